@@ -1,0 +1,83 @@
+"""ctypes binding of libfeasthip.so (include/feasthip.h).  No torch types cross the ABI:
+device buffers are passed as raw integer addresses (``tensor.data_ptr()``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfeasthip.so")
+
+
+class FeastHipStats(C.Structure):
+    _fields_ = [
+        ("seconds_total", C.c_double),
+        ("seconds_solve", C.c_double),
+        ("krylov_iterations", C.c_int64),
+        ("spmm_calls", C.c_int64),
+        ("factorizations", C.c_int64),
+        ("max_rel_residual", C.c_double),
+    ]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/feasthip.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_pi, _pd, _pi64 = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+_ps = C.POINTER(FeastHipStats)
+SYMBOLS = {
+    "feasthip_version": (_i, [_pi, _pi]),
+    "feasthip_create": (_i, [C.POINTER(_vp), _i]),
+    "feasthip_destroy": (_i, [_vp]),
+    "feasthip_last_error": (C.c_char_p, [_vp]),
+    "feasthip_set_stream": (_i, [_vp, _vp]),
+    "feasthip_synchronize": (_i, [_vp]),
+    "feasthip_set_dense": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _i64]),
+    "feasthip_set_csr": (_i, [_vp, _i64, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "feasthip_set_contour": (_i, [_vp, _i, _vp, _vp, _d]),
+    "feasthip_set_node_range": (_i, [_vp, _i, _i]),
+    "feasthip_set_solver": (_i, [_vp, _i, _d, _d, _i, _i, _i, _i]),
+    "feasthip_contour_apply": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
+    "feasthip_contour_apply_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
+    "feasthip_orthonormalize": (_i, [_vp, _i64, _vp, _d, _pi]),
+    "feasthip_orthonormalize_dev": (_i, [_vp, _i64, _vp, _d, _pi]),
+    "feasthip_project": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
+    "feasthip_project_dev": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),
+    "feasthip_ritz_residual": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "feasthip_ritz_residual_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "feasthip_matmul": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "feasthip_matmul_dev": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "feasthip_shifted_solve": (_i, [_vp, _d, _d, _i64, _vp, _vp, _ps]),
+    "feasthip_shifted_solve_dev": (_i, [_vp, _d, _d, _i64, _vp, _vp, _ps]),
+    "feasthip_profile_enable": (_i, [_vp, _i]),
+    "feasthip_profile_reset": (_i, [_vp]),
+    "feasthip_profile_get": (_i, [_vp, C.c_char_p, _pd, _pi64]),
+}
+
+_lib = None
+
+
+class FeastHipUnavailable(RuntimeError):
+    """libfeasthip.so is missing or no MI355X is visible.  There is no CPU fallback."""
+
+
+def load_library(path: str | None = None):
+    """dlopen libfeasthip.so and type every entry point.  Needs no GPU."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FeastHipUnavailable(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  feastkit.jl_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,84 @@
+"""User-facing entry points with the reference's names and argument meaning
+(src/interfaces/feast_interfaces.jl:143-379), restricted to the ``:hip`` backend this
+package provides.  Everything else of the reference API stays on the Julia host."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+from .engine import HipEngine
+from .hip_backend import feast_hip_general, feast_hip_hermitian
+from .parameters import feastdefault, feastinit
+from .types import FeastResult
+
+_BACKENDS = ("hip", "auto")   # _normalize_backend whitelist edit, feast_interfaces.jl:44
+
+
+def _is_hermitian(A, tol=0.0):
+    if sp.issparse(A):
+        D = (A - A.conj().T)
+        return D.nnz == 0 or abs(D).max() <= tol
+    return np.array_equal(A, A.conj().T)
+
+
+def _engine(engine, device):
+    return engine if engine is not None else HipEngine(device)
+
+
+def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="direct", solver_tol=0.0,
+          solver_maxiter=500, solver_restart=30, warm_start=False, inner_rtol=None, group=None,
+          engine=None, device=0, Q0=None):
+    """feast(A, [B,] (Emin, Emax); M0, fpm, backend=:hip) for real-symmetric / Hermitian
+    dense (numpy) or sparse (scipy) matrices.  Real input is complexified and the result is
+    real.(q), exactly as feast_sygv!/feast_scsrgv! do (src/dense/feast_dense.jl:362-387).
+    """
+    if interval is None and B is not None and isinstance(B, tuple):
+        B, interval = None, B              # feast(A, (Emin, Emax)) form
+    if backend not in _BACKENDS:
+        raise ValueError(f"Unknown backend '{backend}' (this package provides: hip)")
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Matrix A must be square")
+    if B is not None and B.shape != A.shape:
+        raise ValueError("Matrix B must match size of A")
+    if not _is_hermitian(A):
+        raise ValueError("Matrix A must be Hermitian")
+    if B is not None and not _is_hermitian(B):
+        raise ValueError("Matrix B must be Hermitian positive definite")
+    Emin, Emax = float(interval[0]), float(interval[1])
+    fpm = feastinit() if fpm is None else fpm
+    feastdefault(fpm)
+    N = A.shape[0]
+    M0 = min(int(M0), N)
+    real_input = not (np.iscomplexobj(A.data if sp.issparse(A) else A) or
+                      (B is not None and np.iscomplexobj(B.data if sp.issparse(B) else B)))
+    if sp.issparse(A) and solver in ("direct", "lu"):
+        # the reference's sparse default is UMFPACK; the :hip backend replaces it with the
+        # batched Krylov solver (north_star) -- there is no sparse direct factorisation here
+        solver = "bicgstab"
+    eng = _engine(engine, device)
+    res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
+                              solver_maxiter=solver_maxiter, solver_restart=solver_restart,
+                              warm_start=warm_start, inner_rtol=inner_rtol, group=group, Q0=Q0)
+    if real_input:
+        res = FeastResult(res.lambda_, np.real(res.q), res.M, res.res, res.info, res.epsout, res.loop, res.stats)
+    return res
+
+
+def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend="hip", solver="direct",
+                  solver_tol=0.0, solver_maxiter=500, solver_restart=30, group=None, engine=None, device=0, Q0=None):
+    """feast_general(A, [B,] center, radius; M0, fpm): src/interfaces/feast_interfaces.jl:274-379."""
+    if backend not in _BACKENDS:
+        raise ValueError(f"Unknown backend '{backend}' (this package provides: hip)")
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Matrix A must be square")
+    if not radius > 0:
+        raise ValueError("radius must be positive")
+    fpm = feastinit() if fpm is None else fpm
+    feastdefault(fpm)
+    M0 = min(int(M0), A.shape[0])
+    if sp.issparse(A) and solver in ("direct", "lu"):
+        solver = "bicgstab"
+    eng = _engine(engine, device)
+    return feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver,
+                             solver_tol=solver_tol, solver_maxiter=solver_maxiter,
+                             solver_restart=solver_restart, group=group, Q0=Q0)

@@ -1,0 +1,93 @@
+"""Contour nodes/weights on the host -- tiny, stays outside
+the kernels exactly as in the reference (src/core/feast_tools.jl:212-371)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def _gauss(n):
+    return np.polynomial.legendre.leggauss(n)   # FastGaussQuadrature.gausslegendre(n)
+
+
+def feast_contour(Emin, Emax, fpm):
+    """Half contour for Hermitian problems: src/core/feast_tools.jl:212-284."""
+    ne, fpm16, fpm18 = int(fpm[2]), int(fpm[16]), int(fpm[18])
+    r = (Emax - Emin) / 2.0
+    Emid = Emin + r
+    aspect = fpm18 * 0.01
+    Zne = np.empty(ne, dtype=np.complex128)
+    Wne = np.empty(ne, dtype=np.complex128)
+    if fpm16 == 0:
+        x, w = _gauss(ne)
+    elif fpm16 == 2:
+        raise NotImplementedError("Zolotarev quadrature (fpm[16]=2) is a table lookup kept on the Julia host")
+    for e in range(ne):
+        if fpm16 == 0:
+            theta = -math.pi / 2 * x[e] + math.pi / 2
+            fac = 0.25 * w[e]
+        else:
+            theta = math.pi - (math.pi / ne) / 2 - (math.pi / ne) * e
+            fac = 1.0 / (2 * ne)
+        Zne[e] = Emid + r * math.cos(theta) + 1j * r * aspect * math.sin(theta)
+        Wne[e] = fac * (r * 1j * math.sin(theta) + r * aspect * math.cos(theta))
+    return Zne, Wne
+
+
+def feast_gcontour(Emid, r, fpm):
+    """Full contour for general problems: src/core/feast_tools.jl:286-371."""
+    ne, fpm16, fpm18, fpm19 = int(fpm[8]), int(fpm[16]), int(fpm[18]), int(fpm[19])
+    Emid = complex(Emid)
+    aspect = fpm18 * 0.01
+    rot = (fpm19 / 180.0) * math.pi
+    nr = r * (math.cos(rot) + 1j * math.sin(rot))
+    Zne = np.empty(ne, dtype=np.complex128)
+    Wne = np.empty(ne, dtype=np.complex128)
+
+    def point(theta, fac, e):
+        Zne[e] = Emid + nr * math.cos(theta) + nr * 1j * aspect * math.sin(theta)
+        Wne[e] = fac * (nr * 1j * math.sin(theta) + nr * aspect * math.cos(theta))
+
+    if fpm16 == 0:
+        nu = ne // 2
+        if nu > 0:
+            xu, wu = _gauss(nu)
+        xl, wl = _gauss(ne - nu)
+        for e in range(nu):
+            point(-math.pi / 2 * xu[e] + math.pi / 2, 0.25 * wu[e], e)
+        for e in range(nu, ne):
+            i = e - nu
+            point(math.pi / 2 * xl[i] - math.pi / 2, 0.25 * wl[i], e)
+    else:
+        for e in range(ne):
+            point(math.pi - (2 * math.pi / ne) / 2 - (2 * math.pi / ne) * e, 1.0 / ne, e)
+    return Zne, Wne
+
+
+def feast_inside_gcontour(lam, Emid, r, fpm=None):
+    """src/core/feast_tools.jl:623-650."""
+    w = complex(lam) - complex(Emid)
+    aspect, rot = 1.0, 0.0
+    if fpm is not None and len(fpm) > 19:
+        if fpm[18] > 0:
+            aspect = fpm[18] * 0.01
+        if fpm[19] != 0:
+            rot = (fpm[19] / 180.0) * math.pi
+    if rot != 0.0:
+        w *= complex(math.cos(-rot), math.sin(-rot))
+    x = w.real / r
+    y = w.imag / (r * aspect)
+    return x * x + y * y <= 1.0
+
+
+def distribute_contour_points(ne, nw):
+    """Contiguous block partition, first ne % nw parts get one extra:
+    src/parallel/feast_parallel.jl:433-447 (returns (first, count) per worker, 0-based)."""
+    per, rem = divmod(ne, nw)
+    out, start = [], 0
+    for i in range(nw):
+        size = per + (1 if i < rem else 0)
+        out.append((start, size))
+        start += size
+    return out

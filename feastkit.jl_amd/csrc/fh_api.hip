@@ -1,0 +1,1091 @@
+// fh_api.hip -- the C ABI of libfeasthip.so (include/feasthip.h).  Host-side orchestration
+// of the gfx950 kernels; no arithmetic on the host except M0 x M0 bookkeeping.
+#include "fh_common.hpp"
+#include "fh_kernels.hpp"
+#include "fh_dense.hpp"
+#include "../../include/feasthip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+// ---------------------------------------------------------------------------------------
+// workspace + profiling helpers
+// ---------------------------------------------------------------------------------------
+int fh_get_buf(feasthip_ctx* h, const char* name, size_t bytes, void** out) {
+    auto it = h->bufs.find(name);
+    if (it != h->bufs.end() && it->second.second >= bytes) {
+        *out = it->second.first;
+        return 0;
+    }
+    if (it != h->bufs.end()) {
+        hipStreamSynchronize(h->stream);
+        hipFree(it->second.first);
+        h->bufs.erase(it);
+    }
+    void* p = nullptr;
+    size_t alloc = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&p, alloc);
+    if (e != hipSuccess) {
+        h->last_error = std::string("hipMalloc(") + name + ", " + std::to_string(alloc) + "): " + hipGetErrorString(e);
+        return FEASTHIP_ERROR_MEMORY;
+    }
+    h->bufs[name] = {p, alloc};
+    *out = p;
+    return 0;
+}
+
+void fh_free_bufs(feasthip_ctx* h) {
+    for (auto& kv : h->bufs) hipFree(kv.second.first);
+    h->bufs.clear();
+}
+
+// Sampled event timing: every FH_PROF_PERIOD-th launch of a class is bracketed by two events
+// on the launch stream; the class average is (sum of sampled durations)/(samples).
+#define FH_PROF_PERIOD 4
+static thread_local int fh_prof_open = 0;
+void fh_prof_begin(feasthip_ctx* h, const char* cls) {
+    fh_prof_open = 0;
+    if (!h->profiling) return;
+    fh_prof_class& pc = h->prof[cls];
+    pc.launches += 1;
+    if ((pc.launches % FH_PROF_PERIOD) != 1 && FH_PROF_PERIOD > 1) return;
+    if (h->pending_events.size() > 60000) return;
+    fh_event_pair ep;
+    ep.cls = cls;
+    if (hipEventCreate(&ep.a) != hipSuccess) return;
+    if (hipEventCreate(&ep.b) != hipSuccess) { hipEventDestroy(ep.a); return; }
+    hipEventRecord(ep.a, h->stream);
+    h->pending_events.push_back(ep);
+    fh_prof_open = 1;
+}
+void fh_prof_end(feasthip_ctx* h) {
+    if (!fh_prof_open) return;
+    hipEventRecord(h->pending_events.back().b, h->stream);
+    fh_prof_open = 0;
+}
+void fh_prof_collect(feasthip_ctx* h) {
+    if (h->pending_events.empty()) return;
+    hipStreamSynchronize(h->stream);
+    for (auto& ep : h->pending_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            fh_prof_class& pc = h->prof[ep.cls + std::string("#sampled")];
+            pc.total_ms += ms;
+            pc.launches += 1;
+        }
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    h->pending_events.clear();
+}
+
+// ---------------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------------
+extern "C" int feasthip_version(int* major, int* minor) {
+    if (major) *major = FEASTHIP_VERSION_MAJOR;
+    if (minor) *minor = FEASTHIP_VERSION_MINOR;
+    return 0;
+}
+
+extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
+    if (!out) return FEASTHIP_ERROR_INTERNAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FEASTHIP_ERROR_INTERNAL;
+    if (device_id < 0 || device_id >= ndev) return FEASTHIP_ERROR_INTERNAL;
+    feasthip_ctx* h = new (std::nothrow) feasthip_ctx();
+    if (!h) return FEASTHIP_ERROR_MEMORY;
+    h->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
+    h->stream = h->own_stream;
+    *out = h;
+    return 0;
+}
+
+static void fh_free_problem(feasthip_ctx* h) {
+    if (h->csr.rowptr) hipFree(h->csr.rowptr);
+    if (h->csr.col) hipFree(h->csr.col);
+    if (h->csr.aval) hipFree(h->csr.aval);
+    if (h->csr.bval) hipFree(h->csr.bval);
+    h->csr = fh_csr();
+    if (h->dense.A) hipFree(h->dense.A);
+    if (h->dense.B) hipFree(h->dense.B);
+    h->dense = fh_dense();
+    for (void* p : h->lu_factors) if (p) hipFree(p);
+    for (int* p : h->lu_pivots) if (p) hipFree(p);
+    h->lu_factors.clear(); h->lu_pivots.clear(); h->lu_valid.clear(); h->lu_z.clear();
+    h->kind = 0;
+}
+
+extern "C" int feasthip_destroy(feasthip_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    fh_prof_collect(h);
+    fh_free_problem(h);
+    fh_free_bufs(h);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+
+extern "C" const char* feasthip_last_error(feasthip_handle h) { return h ? h->last_error.c_str() : "null handle"; }
+
+extern "C" int feasthip_set_stream(feasthip_handle h, void* hip_stream) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    hipStreamSynchronize(h->stream);
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return 0;
+}
+
+extern "C" int feasthip_synchronize(feasthip_handle h) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    FH_CHECK(hipSetDevice(h->device));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_prof_collect(h);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// problem definition
+// ---------------------------------------------------------------------------------------
+template <typename VT>
+struct host_csr {
+    std::vector<int64_t> ptr, idx;
+    std::vector<VT> val;
+};
+
+// Convert (CSR|CSC, base) input to 0-based CSR with sorted rows.
+template <typename VT>
+static bool to_csr0(int64_t N, int index_base, int storage, int64_t nnz, const int64_t* ptr, const int64_t* idx,
+                    const VT* val, host_csr<VT>& out) {
+    for (int64_t i = 0; i <= N; ++i)
+        if (ptr[i] - index_base < 0 || ptr[i] - index_base > nnz) return false;
+    for (int64_t k = 0; k < nnz; ++k)
+        if (idx[k] - index_base < 0 || idx[k] - index_base >= N) return false;
+    out.ptr.assign(N + 1, 0);
+    out.idx.resize(nnz);
+    out.val.resize(nnz);
+    if (storage == FEASTHIP_STORAGE_CSR) {
+        for (int64_t i = 0; i <= N; ++i) out.ptr[i] = ptr[i] - index_base;
+        for (int64_t k = 0; k < nnz; ++k) { out.idx[k] = idx[k] - index_base; out.val[k] = val[k]; }
+    } else {
+        // CSC -> CSR: counting transpose (entry (r, c) stored in column c)
+        for (int64_t k = 0; k < nnz; ++k) out.ptr[idx[k] - index_base + 1]++;
+        for (int64_t i = 0; i < N; ++i) out.ptr[i + 1] += out.ptr[i];
+        std::vector<int64_t> fill(out.ptr.begin(), out.ptr.end() - 1);
+        for (int64_t c = 0; c < N; ++c)
+            for (int64_t k = ptr[c] - index_base; k < ptr[c + 1] - index_base; ++k) {
+                int64_t r = idx[k] - index_base;
+                int64_t o = fill[r]++;
+                out.idx[o] = c;
+                out.val[o] = val[k];
+            }
+    }
+    // sort each row by column (insertion sort: rows are short / mostly sorted)
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t a = out.ptr[i], b = out.ptr[i + 1];
+        bool sorted = true;
+        for (int64_t k = a + 1; k < b; ++k) if (out.idx[k] < out.idx[k - 1]) { sorted = false; break; }
+        if (sorted) continue;
+        std::vector<std::pair<int64_t, VT>> row;
+        row.reserve(b - a);
+        for (int64_t k = a; k < b; ++k) row.push_back({out.idx[k], out.val[k]});
+        std::stable_sort(row.begin(), row.end(), [](const std::pair<int64_t, VT>& x, const std::pair<int64_t, VT>& y) { return x.first < y.first; });
+        for (int64_t k = a; k < b; ++k) { out.idx[k] = row[k - a].first; out.val[k] = row[k - a].second; }
+    }
+    return true;
+}
+
+static inline double vzero(double) { return 0.0; }
+static inline cplx vzero(cplx) { return cmake(0, 0); }
+static inline double vadd(double a, double b) { return a + b; }
+static inline cplx vadd(cplx a, cplx b) { return cadd(a, b); }
+
+template <typename VT>
+static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage, int64_t nnzA, const int64_t* ptrA,
+                         const int64_t* idxA, const VT* valA, int64_t nnzB, const int64_t* ptrB, const int64_t* idxB,
+                         const VT* valB) {
+    host_csr<VT> A, B;
+    if (!to_csr0<VT>(N, index_base, storage, nnzA, ptrA, idxA, valA, A)) {
+        h->last_error = "feasthip_set_csr: malformed A (pointer/index out of range)";
+        return FEASTHIP_ERROR_N;
+    }
+    const bool hasB = ptrB != nullptr;
+    if (hasB && !to_csr0<VT>(N, index_base, storage, nnzB, ptrB, idxB, valB, B)) {
+        h->last_error = "feasthip_set_csr: malformed B (pointer/index out of range)";
+        return FEASTHIP_ERROR_N;
+    }
+    // union pattern, duplicates summed
+    std::vector<int> rowptr(N + 1, 0), col;
+    std::vector<VT> av, bv;
+    col.reserve(nnzA + (hasB ? nnzB : 0));
+    av.reserve(col.capacity());
+    if (hasB) bv.reserve(col.capacity());
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t ka = A.ptr[i], ea = A.ptr[i + 1];
+        int64_t kb = hasB ? B.ptr[i] : 0, eb = hasB ? B.ptr[i + 1] : 0;
+        while (ka < ea || kb < eb) {
+            int64_t ca = ka < ea ? A.idx[ka] : INT64_MAX;
+            int64_t cb = kb < eb ? B.idx[kb] : INT64_MAX;
+            int64_t c = std::min(ca, cb);
+            VT a = vzero(VT()), b = vzero(VT());
+            while (ka < ea && A.idx[ka] == c) { a = vadd(a, A.val[ka]); ++ka; }
+            while (kb < eb && B.idx[kb] == c) { b = vadd(b, B.val[kb]); ++kb; }
+            col.push_back((int)c);
+            av.push_back(a);
+            if (hasB) bv.push_back(b);
+        }
+        if (col.size() > (size_t)INT32_MAX) { h->last_error = "feasthip_set_csr: nnz exceeds int32"; return FEASTHIP_ERROR_MEMORY; }
+        rowptr[i + 1] = (int)col.size();
+    }
+    fh_free_problem(h);
+    fh_csr& d = h->csr;
+    d.N = N; d.nnz = (int64_t)col.size(); d.is_complex = sizeof(VT) == sizeof(cplx); d.b_identity = hasB ? 0 : 1;
+    FH_CHECK(hipMalloc((void**)&d.rowptr, (N + 1) * sizeof(int)));
+    FH_CHECK(hipMalloc((void**)&d.col, std::max<size_t>(1, col.size()) * sizeof(int)));
+    FH_CHECK(hipMalloc(&d.aval, std::max<size_t>(1, col.size()) * sizeof(VT)));
+    FH_CHECK(hipMemcpy(d.rowptr, rowptr.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice));
+    FH_CHECK(hipMemcpy(d.col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
+    FH_CHECK(hipMemcpy(d.aval, av.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
+    if (hasB) {
+        FH_CHECK(hipMalloc(&d.bval, std::max<size_t>(1, col.size()) * sizeof(VT)));
+        FH_CHECK(hipMemcpy(d.bval, bv.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
+    }
+    h->kind = 2;
+    return 0;
+}
+
+extern "C" int feasthip_set_csr(feasthip_handle h, int64_t N, int is_complex, int index_base, int storage,
+                                int64_t nnzA, const int64_t* ptrA, const int64_t* idxA, const void* valA,
+                                int64_t nnzB, const int64_t* ptrB, const int64_t* idxB, const void* valB) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (N <= 0 || N > INT32_MAX / FH_MAX_LD) { h->last_error = "feasthip_set_csr: N out of range"; return FEASTHIP_ERROR_N; }
+    if (!ptrA || (nnzA > 0 && (!idxA || !valA))) { h->last_error = "feasthip_set_csr: null A"; return FEASTHIP_ERROR_N; }
+    if (index_base != 0 && index_base != 1) { h->last_error = "feasthip_set_csr: index_base must be 0 or 1"; return FEASTHIP_ERROR_FPM; }
+    if (storage != FEASTHIP_STORAGE_CSR && storage != FEASTHIP_STORAGE_CSC) { h->last_error = "feasthip_set_csr: bad storage"; return FEASTHIP_ERROR_FPM; }
+    FH_CHECK(hipSetDevice(h->device));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (is_complex)
+        return set_csr_typed<cplx>(h, N, index_base, storage, nnzA, ptrA, idxA, (const cplx*)valA, nnzB, ptrB, idxB, (const cplx*)valB);
+    return set_csr_typed<double>(h, N, index_base, storage, nnzA, ptrA, idxA, (const double*)valA, nnzB, ptrB, idxB, (const double*)valB);
+}
+
+extern "C" int feasthip_set_dense(feasthip_handle h, int64_t N, int is_complex, const void* A, int64_t lda,
+                                  const void* B, int64_t ldb) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (N <= 0 || N > 65536) { h->last_error = "feasthip_set_dense: N out of range"; return FEASTHIP_ERROR_N; }
+    if (!A || lda < N || (B && ldb < N)) { h->last_error = "feasthip_set_dense: bad A/lda/ldb"; return FEASTHIP_ERROR_N; }
+    FH_CHECK(hipSetDevice(h->device));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_free_problem(h);
+    size_t es = is_complex ? sizeof(cplx) : sizeof(double);
+    fh_dense& d = h->dense;
+    d.N = N; d.is_complex = is_complex; d.b_identity = B ? 0 : 1;
+    FH_CHECK(hipMalloc(&d.A, (size_t)N * N * es));
+    FH_CHECK(hipMemcpy2D(d.A, (size_t)N * es, A, (size_t)lda * es, (size_t)N * es, (size_t)N, hipMemcpyHostToDevice));
+    if (B) {
+        FH_CHECK(hipMalloc(&d.B, (size_t)N * N * es));
+        FH_CHECK(hipMemcpy2D(d.B, (size_t)N * es, B, (size_t)ldb * es, (size_t)N * es, (size_t)N, hipMemcpyHostToDevice));
+    }
+    h->kind = 1;
+    return 0;
+}
+
+extern "C" int feasthip_set_contour(feasthip_handle h, int ne, const double* zne, const double* wne, double weight_scale) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (ne <= 0 || !zne || !wne) { h->last_error = "feasthip_set_contour: ne <= 0 or null arrays"; return FEASTHIP_ERROR_FPM; }
+    h->zne.resize(ne); h->wne.resize(ne);
+    for (int e = 0; e < ne; ++e) {
+        h->zne[e] = cmake(zne[2 * e], zne[2 * e + 1]);
+        h->wne[e] = cmake(wne[2 * e], wne[2 * e + 1]);
+    }
+    h->weight_scale = weight_scale;
+    h->node_first = 0;
+    h->node_count = ne;
+    // cached factors belong to the old contour
+    for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
+    return 0;
+}
+
+extern "C" int feasthip_set_node_range(feasthip_handle h, int first, int count) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (first < 0 || count < 0 || first + count > (int)h->zne.size()) {
+        h->last_error = "feasthip_set_node_range: range outside the contour";
+        return FEASTHIP_ERROR_FPM;
+    }
+    h->node_first = first;
+    h->node_count = count;
+    for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
+    return 0;
+}
+
+extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit, int restart,
+                                   int factor_precision, int cache_factors) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (kind < 0 || kind > 2 || rtol < 0 || atol < 0 || maxit <= 0 || restart < 0 ||
+        (factor_precision != 64 && factor_precision != 32)) {
+        h->last_error = "feasthip_set_solver: invalid option";
+        return FEASTHIP_ERROR_FPM;
+    }
+    h->solver = kind; h->rtol = rtol; h->atol = atol; h->maxit = maxit; h->restart = restart;
+    h->factor_precision = factor_precision; h->cache_factors = cache_factors;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// operator application on panels (sparse or dense):  Y = (cb*B + ca*A) X  per column
+// ---------------------------------------------------------------------------------------
+static int fh_spmm_nblk(int N) {
+    int nb = (N + 15) / 16;
+    if (nb > 2048) nb = 2048;
+    if (nb < 8) nb = 8;
+    return (nb + 7) / 8 * 8;
+}
+
+struct fh_op_call {
+    const cplx* X; size_t x_stride;
+    cplx* Y; size_t y_stride;
+    const cplx* coefA; const cplx* coefB;   // device [nodes][ld]
+    const cplx* Bvec; size_t b_stride;
+    const cplx* U; size_t u_stride;
+    int dot_mode; cplx* partial1; cplx* partial2;
+    const int* node_active;
+    int nodes;
+};
+
+// returns number of blocks used in x (needed to size / read partials)
+static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
+    if (h->kind == 2) {
+        fh_spmm_args a;
+        a.rowptr = h->csr.rowptr; a.col = h->csr.col; a.aval = h->csr.aval; a.bval = h->csr.bval;
+        a.N = (int)h->csr.N; a.nodes = c.nodes;
+        a.X = c.X; a.x_node_stride = c.x_stride; a.Y = c.Y; a.y_node_stride = c.y_stride;
+        a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = c.Bvec; a.b_node_stride = c.b_stride;
+        a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
+        a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
+        int nblk = fh_spmm_nblk(a.N);
+        fh_prof_begin(h, "spmm");
+        fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, nblk, h->stream);
+        fh_prof_end(h);
+        return nblk;
+    }
+    fh_dense_op_args a;
+    a.A = h->dense.A; a.B = h->dense.B; a.N = (int)h->dense.N; a.is_complex = h->dense.is_complex;
+    a.nodes = c.nodes; a.X = c.X; a.x_node_stride = c.x_stride; a.Y = c.Y; a.y_node_stride = c.y_stride;
+    a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = c.Bvec; a.b_node_stride = c.b_stride;
+    a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
+    a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
+    int nblk = fh_dense_op_nblk(a.N);
+    fh_prof_begin(h, "dense_op");
+    fh_launch_dense_op(a, ld, nblk, h->stream);
+    fh_prof_end(h);
+    return nblk;
+}
+
+static int fh_op_nblk(feasthip_ctx* h) {
+    return h->kind == 2 ? fh_spmm_nblk((int)h->csr.N) : fh_dense_op_nblk((int)h->dense.N);
+}
+static int64_t fh_N(feasthip_ctx* h) { return h->kind == 2 ? h->csr.N : h->dense.N; }
+static bool fh_b_identity(feasthip_ctx* h) { return h->kind == 2 ? h->csr.b_identity != 0 : h->dense.b_identity != 0; }
+
+static int fh_check_problem(feasthip_ctx* h, int64_t m) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->kind == 0) { h->last_error = "no matrix set (feasthip_set_dense / feasthip_set_csr)"; return FEASTHIP_ERROR_N; }
+    if (m <= 0 || m > FH_MAX_LD || m > fh_N(h)) {
+        h->last_error = "block width m must satisfy 1 <= m <= min(N, 64)";
+        return FEASTHIP_ERROR_M0;
+    }
+    return 0;
+}
+
+// upload per-column coefficient arrays [nodes][ld]
+static int fh_upload_coefs(feasthip_ctx* h, const char* name, const std::vector<cplx>& host, cplx** dev) {
+    void* p = nullptr;
+    int rc = fh_get_buf(h, name, host.size() * sizeof(cplx), &p);
+    if (rc) return rc;
+    FH_CHECK(hipMemcpyAsync(p, host.data(), host.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));   // host vector may go out of scope
+    *dev = (cplx*)p;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// batched BiCGStab on panels:  solve (z_e B - A) X_e = RHS for e in [0, nodes)
+// X holds the initial guess on entry.  All arrays are device panels (N x ld), node-strided.
+// ---------------------------------------------------------------------------------------
+struct fh_solve_result {
+    int64_t iters_sum = 0;      // sum over nodes of max column iterations
+    int64_t op_calls = 0;
+    int max_iters = 0;
+    std::vector<int> status;    // per node
+    double max_rel_res = 0.0;
+};
+
+static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
+                       cplx* X, size_t stride, fh_solve_result& res) {
+    const int N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    int rc;
+    void* p;
+    // vectors R, Rhat, P, V, S, T
+    if ((rc = fh_get_buf(h, "kry_vecs", 6 * nodes * panel * sizeof(cplx), &p))) return rc;
+    cplx* base = (cplx*)p;
+    cplx *R = base, *Rh = base + nodes * panel, *P = base + 2 * nodes * panel, *V = base + 3 * nodes * panel,
+         *S = base + 4 * nodes * panel, *T = base + 5 * nodes * panel;
+    // scalars
+    const size_t nl = (size_t)nodes * ld;
+    if ((rc = fh_get_buf(h, "kry_scal_c", 4 * nl * sizeof(cplx), &p))) return rc;
+    fh_krylov_scalars s;
+    s.rho = (cplx*)p; s.alpha = s.rho + nl; s.omega = s.alpha + nl; s.beta = s.omega + nl;
+    if ((rc = fh_get_buf(h, "kry_scal_d", 3 * nl * sizeof(double), &p))) return rc;
+    s.r0norm = (double*)p; s.target = s.r0norm + nl; s.rnorm = s.target + nl;
+    if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
+    s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
+    int* d_count = s.node_active + nodes;
+    const int nblk_op = fh_op_nblk(h);
+    const int nblk_vec = fh_vec_nblk(N, ld);
+    const int nblk_max = std::max(nblk_op, nblk_vec);
+    if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
+    cplx* part1 = (cplx*)p;
+    cplx* part2 = part1 + (size_t)nodes * nblk_max * ld;
+
+    // shifted-operator coefficients: S_e = z_e B - A
+    std::vector<cplx> ca(nl), cb(nl);
+    for (int e = 0; e < nodes; ++e)
+        for (int c = 0; c < ld; ++c) { ca[e * ld + c] = cmake(-1, 0); cb[e * ld + c] = z[e]; }
+    cplx *dca, *dcb;
+    if ((rc = fh_upload_coefs(h, "kry_coefA", ca, &dca))) return rc;
+    if ((rc = fh_upload_coefs(h, "kry_coefB", cb, &dcb))) return rc;
+
+    int* h_count = nullptr;
+    FH_CHECK(hipHostMalloc((void**)&h_count, sizeof(int)));
+
+    fh_vec_args va;
+    va.N = N; va.node_stride = stride; va.X = X; va.R = R; va.Rhat = Rh; va.P = P; va.V = V; va.S = S; va.T = T;
+    va.Q = nullptr; va.lambda = nullptr; va.znode = nullptr; va.s = s; va.partial1 = part1; va.partial2 = part2;
+    // note: R/Rhat/P/V/S/T use the packed stride `panel`; X may use a different stride
+    fh_vec_args vw = va;   // work vectors view with stride = panel
+    (void)vw;
+
+    // R = RHS - S X0, ||R||^2
+    fh_op_call oc;
+    oc.X = X; oc.x_stride = stride; oc.Y = R; oc.y_stride = panel; oc.coefA = dca; oc.coefB = dcb;
+    oc.Bvec = RHS; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 3;
+    oc.partial1 = part1; oc.partial2 = part2; oc.node_active = nullptr; oc.nodes = nodes;
+    int nb = fh_apply_operator(h, ld, oc);
+    res.op_calls += 1;
+    fh_fin_args fa;
+    fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.nblk = nb; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
+    fh_launch_fin_init(fa, ld, nodes, h->stream);
+    // Rhat = R ; P = R
+    fh_vec_args vc = va;
+    vc.node_stride = panel;
+    fh_launch_copy_r(vc, ld, nblk_vec, nodes, h->stream);
+
+    const int check_every = 8;
+    int it = 0;
+    bool all_done = false;
+    while (it < h->maxit && !all_done) {
+        int chunk = std::min(check_every, h->maxit - it);
+        for (int k = 0; k < chunk; ++k) {
+            // V = S P, sigma = <Rhat, V>
+            oc.X = P; oc.x_stride = panel; oc.Y = V; oc.y_stride = panel; oc.Bvec = nullptr; oc.U = Rh; oc.u_stride = panel;
+            oc.dot_mode = 1; oc.node_active = s.node_active;
+            nb = fh_apply_operator(h, ld, oc);
+            fa.nblk = nb;
+            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_alpha(fa, ld, nodes, h->stream); fh_prof_end(h);
+            // S = R - alpha V
+            fh_prof_begin(h, "bicg_s"); fh_launch_s_update(vc, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+            // T = S S, <T,S>, <T,T>
+            oc.X = S; oc.Y = T; oc.U = nullptr; oc.dot_mode = 2;
+            nb = fh_apply_operator(h, ld, oc);
+            fa.nblk = nb;
+            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_omega(fa, ld, nodes, h->stream); fh_prof_end(h);
+            // X += alpha P + omega S ; R = S - omega T ; rho_new, ||R||
+            {
+                // X uses `stride`, the work vectors use `panel`: pass X pre-offset per node via stride
+                fh_vec_args vx = vc;
+                vx.X = X;
+                // k_xr_update indexes every array with node_stride; X needs its own stride
+                if (stride != panel) { h->last_error = "internal: solution stride mismatch"; hipHostFree(h_count); return FEASTHIP_ERROR_INTERNAL; }
+                fh_prof_begin(h, "bicg_xr"); fh_launch_xr_update(vx, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+            }
+            fa.nblk = nblk_vec;
+            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
+            // P = R + beta (P - omega V)
+            fh_prof_begin(h, "bicg_p"); fh_launch_p_update(vc, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+            res.op_calls += 2;
+        }
+        it += chunk;
+        fh_launch_count_active(s.node_active, nodes, d_count, h->stream);
+        FH_CHECK(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        all_done = (*h_count == 0);
+    }
+    hipHostFree(h_count);
+
+    // gather per-column bookkeeping
+    std::vector<int> iters(nl), status(nl), active(nl);
+    std::vector<double> rnorm(nl), r0(nl);
+    FH_CHECK(hipMemcpy(iters.data(), s.iters, nl * sizeof(int), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(status.data(), s.status, nl * sizeof(int), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(active.data(), s.active, nl * sizeof(int), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(rnorm.data(), s.rnorm, nl * sizeof(double), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(r0.data(), s.r0norm, nl * sizeof(double), hipMemcpyDeviceToHost));
+    res.status.assign(nodes, 0);
+    for (int e = 0; e < nodes; ++e) {
+        int mx = 0, st = 0;
+        for (int c = 0; c < m; ++c) {
+            int i = e * ld + c;
+            mx = std::max(mx, iters[i]);
+            if (active[i]) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
+            else if (status[i] == 8 && !(rnorm[i] <= h->atol + h->rtol * r0[i])) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
+            if (r0[i] > 0) res.max_rel_res = std::max(res.max_rel_res, rnorm[i] / r0[i]);
+        }
+        res.iters_sum += mx;
+        res.max_iters = std::max(res.max_iters, mx);
+        res.status[e] = st;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// contour sweep
+// ---------------------------------------------------------------------------------------
+static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
+                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+    int rc = fh_check_problem(h, m64);
+    if (rc) return rc;
+    if (h->zne.empty()) { h->last_error = "no contour set"; return FEASTHIP_ERROR_FPM; }
+    auto t0 = std::chrono::steady_clock::now();
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    const int nodes = h->node_count;
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "ca_Qp", panel * sizeof(cplx), &p))) return rc;
+    cplx* Qp = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ca_out", panel * sizeof(cplx), &p))) return rc;
+    cplx* Outp = (cplx*)p;
+    fh_launch_to_panel(dQ, N, N, m, Qp, ld, h->stream);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (nodes == 0) {
+        FH_CHECK(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream));
+        if (dzAq) FH_CHECK(hipMemsetAsync(dzAq, 0, (size_t)m * m * sizeof(cplx), h->stream));
+        if (dzSq) FH_CHECK(hipMemsetAsync(dzSq, 0, (size_t)m * m * sizeof(cplx), h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    // rhs = B Q  (hoisted out of the node loop; the reference recomputes it per node,
+    // src/dense/feast_dense.jl:184 -- it is loop invariant)
+    cplx* Rhs = Qp;
+    if (!fh_b_identity(h)) {
+        if ((rc = fh_get_buf(h, "ca_rhs", panel * sizeof(cplx), &p))) return rc;
+        Rhs = (cplx*)p;
+        std::vector<cplx> ca(ld, cmake(0, 0)), cb(ld, cmake(1, 0));
+        cplx *dca, *dcb;
+        if ((rc = fh_upload_coefs(h, "ca_coefA", ca, &dca))) return rc;
+        if ((rc = fh_upload_coefs(h, "ca_coefB", cb, &dcb))) return rc;
+        fh_op_call oc;
+        oc.X = Qp; oc.x_stride = 0; oc.Y = Rhs; oc.y_stride = 0; oc.coefA = dca; oc.coefB = dcb;
+        oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+        oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+        fh_apply_operator(h, ld, oc);
+    }
+    std::vector<cplx> z(nodes), w(nodes);
+    for (int e = 0; e < nodes; ++e) {
+        z[e] = h->zne[h->node_first + e];
+        w[e] = cscale(h->wne[h->node_first + e], h->weight_scale);
+    }
+    if ((rc = fh_get_buf(h, "ca_Y", (size_t)nodes * panel * sizeof(cplx), &p))) return rc;
+    cplx* Y = (cplx*)p;
+    std::vector<int> status(nodes, 0);
+
+    hipEvent_t ev0, ev1;
+    FH_CHECK(hipEventCreate(&ev0)); FH_CHECK(hipEventCreate(&ev1));
+    FH_CHECK(hipEventRecord(ev0, h->stream));
+    if (h->solver == FEASTHIP_SOLVER_LU) {
+        if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix (sparse direct factorisation is not provided; use BICGSTAB)"; return FEASTHIP_ERROR_FPM; }
+        int64_t nfact = 0;
+        rc = fh_dense_lu_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
+        if (rc) return rc;
+        if (stats) stats->factorizations = nfact;
+    } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB) {
+        // initial guess
+        cplx* dz;
+        if ((rc = fh_upload_coefs(h, "ca_z", z, &dz))) return rc;
+        double* dlam = nullptr;
+        if (ritz_lambda) {
+            std::vector<double> lam(ld, 0.0);
+            for (int c = 0; c < m; ++c) lam[c] = ritz_lambda[c];
+            if ((rc = fh_get_buf(h, "ca_lam", ld * sizeof(double), &p))) return rc;
+            dlam = (double*)p;
+            FH_CHECK(hipMemcpy(dlam, lam.data(), ld * sizeof(double), hipMemcpyHostToDevice));
+        }
+        fh_vec_args va;
+        memset(&va, 0, sizeof(va));
+        va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz;
+        fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
+        fh_solve_result sr;
+        rc = fh_bicgstab(h, ld, m, nodes, z, Rhs, Y, panel, sr);
+        if (rc) return rc;
+        status = sr.status;
+        if (stats) {
+            stats->krylov_iterations = sr.iters_sum;
+            stats->spmm_calls = sr.op_calls;
+            stats->max_rel_residual = sr.max_rel_res;
+        }
+    } else {
+        h->last_error = "solver GMRES is not implemented on the device yet; use BICGSTAB";
+        return FEASTHIP_ERROR_FPM;
+    }
+    FH_CHECK(hipEventRecord(ev1, h->stream));
+
+    // Q_proj = sum_e (scale*w_e) Y_e
+    cplx* dw;
+    if ((rc = fh_upload_coefs(h, "ca_w", w, &dw))) return rc;
+    fh_prof_begin(h, "accumulate");
+    fh_launch_accumulate(Y, panel, dw, nodes, N, ld, Outp, h->stream);
+    fh_prof_end(h);
+    fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream);
+
+    // optional moments (variant B): zAq += w_e Q^H Y_e ; zSq += w_e z_e Q^H Y_e
+    if (dzAq || dzSq) {
+        if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
+        cplx* gw = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gram_G", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+        cplx* G = (cplx*)p;
+        std::vector<cplx> Gh((size_t)ld * ld), aq((size_t)m * m, cmake(0, 0)), sq((size_t)m * m, cmake(0, 0));
+        for (int e = 0; e < nodes; ++e) {
+            fh_prof_begin(h, "gram");
+            fh_launch_gram(Qp, Y + (size_t)e * panel, N, ld, 0, gw, G, h->stream);
+            fh_prof_end(h);
+            FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+            FH_CHECK(hipStreamSynchronize(h->stream));
+            cplx wz = cmul(w[e], z[e]);
+            for (int c2 = 0; c2 < m; ++c2)
+                for (int c1 = 0; c1 < m; ++c1) {
+                    cplx g = Gh[(size_t)c2 * ld + c1];
+                    cfma(aq[(size_t)c2 * m + c1], w[e], g);
+                    cfma(sq[(size_t)c2 * m + c1], wz, g);
+                }
+        }
+        if (dzAq) FH_CHECK(hipMemcpyAsync(dzAq, aq.data(), aq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+        if (dzSq) FH_CHECK(hipMemcpyAsync(dzSq, sq.data(), sq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+    }
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = status[e];
+    if (stats) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev0, ev1);
+        stats->seconds_solve = ms * 1e-3;
+        stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    hipEventDestroy(ev0); hipEventDestroy(ev1);
+    fh_prof_collect(h);
+    return 0;
+}
+
+extern "C" int feasthip_contour_apply_dev(feasthip_handle h, int64_t m, const void* dQ, const double* ritz_lambda_host,
+                                          void* dQproj, void* dzAq, void* dzSq, int* node_status, feasthip_stats* stats) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (!dQ || !dQproj) { h->last_error = "contour_apply: null Q/Qproj"; return FEASTHIP_ERROR_INTERNAL; }
+    return fh_contour_apply_impl(h, m, (const cplx*)dQ, ritz_lambda_host, (cplx*)dQproj, (cplx*)dzAq, (cplx*)dzSq, node_status, stats);
+}
+
+// host-pointer wrapper helpers
+static int fh_stage_in(feasthip_ctx* h, const char* name, const void* host, size_t bytes, void** dev) {
+    int rc = fh_get_buf(h, name, bytes, dev);
+    if (rc) return rc;
+    FH_CHECK(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+extern "C" int feasthip_contour_apply(feasthip_handle h, int64_t m, const void* Q, const double* ritz_lambda,
+                                      void* Qproj, void* zAq, void* zSq, int* node_status, feasthip_stats* stats) {
+    int rc = fh_check_problem(h, m);
+    if (rc) return rc;
+    if (!Q || !Qproj) { h->last_error = "contour_apply: null Q/Qproj"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const size_t nb = (size_t)fh_N(h) * m * sizeof(cplx), mb = (size_t)m * m * sizeof(cplx);
+    void *dQ, *dP, *dA = nullptr, *dS = nullptr;
+    if ((rc = fh_stage_in(h, "host_Q", Q, nb, &dQ))) return rc;
+    if ((rc = fh_get_buf(h, "host_Qproj", nb, &dP))) return rc;
+    if (zAq && (rc = fh_get_buf(h, "host_zAq", mb, &dA))) return rc;
+    if (zSq && (rc = fh_get_buf(h, "host_zSq", mb, &dS))) return rc;
+    rc = fh_contour_apply_impl(h, m, (const cplx*)dQ, ritz_lambda, (cplx*)dP, (cplx*)dA, (cplx*)dS, node_status, stats);
+    if (rc) return rc;
+    FH_CHECK(hipMemcpy(Qproj, dP, nb, hipMemcpyDeviceToHost));
+    if (zAq) FH_CHECK(hipMemcpy(zAq, dA, mb, hipMemcpyDeviceToHost));
+    if (zSq) FH_CHECK(hipMemcpy(zSq, dS, mb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// orthonormalisation (a9)
+// ---------------------------------------------------------------------------------------
+extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void* dQ, double rank_tol, int* rank) {
+    int rc = fh_check_problem(h, m64);
+    if (rc) return rc;
+    if (!dQ || !rank) { h->last_error = "orthonormalize: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "or_X", panel * sizeof(cplx), &p))) return rc;
+    cplx* X = (cplx*)p;
+    if ((rc = fh_get_buf(h, "or_out", panel * sizeof(cplx), &p))) return rc;
+    cplx* Out = (cplx*)p;
+    if ((rc = fh_get_buf(h, "or_work", (size_t)1024 * ld * sizeof(cplx), &p))) return rc;
+    cplx* work = (cplx*)p;
+    if ((rc = fh_get_buf(h, "or_istate", (4 + FH_MAX_LD) * sizeof(int), &p))) return rc;
+    int* istate = (int*)p;
+    if ((rc = fh_get_buf(h, "or_dstate", (2 + FH_MAX_LD) * sizeof(double), &p))) return rc;
+    double* dstate = (double*)p;
+    if ((rc = fh_get_buf(h, "or_coef", FH_MAX_LD * sizeof(cplx), &p))) return rc;
+    cplx* coef = (cplx*)p;
+    fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
+    fh_mgs_args a;
+    a.X = X; a.N = N; a.ld = ld; a.m = m; a.istate = istate; a.dstate = dstate; a.coef = coef; a.work = work;
+    a.rank_tol = rank_tol;
+    fh_prof_begin(h, "ortho");
+    fh_mgs_run(a, h->stream);
+    fh_prof_end(h);
+    int hst[4 + FH_MAX_LD];
+    FH_CHECK(hipMemcpyAsync(hst, istate, (4 + ld) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    int r = hst[2] ? hst[1] : hst[0];
+    if (r < 0) r = 0;
+    if (r > m) r = m;
+    *rank = r;
+    fh_launch_gather_cols(X, istate + 4, r, N, ld, Out, h->stream);
+    fh_launch_from_panel(Out, ld, N, m, (cplx*)dQ, N, h->stream);
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_prof_collect(h);
+    return 0;
+}
+
+extern "C" int feasthip_orthonormalize(feasthip_handle h, int64_t m, void* Q, double rank_tol, int* rank) {
+    int rc = fh_check_problem(h, m);
+    if (rc) return rc;
+    if (!Q || !rank) { h->last_error = "orthonormalize: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const size_t nb = (size_t)fh_N(h) * m * sizeof(cplx);
+    void* dQ;
+    if ((rc = fh_stage_in(h, "host_Q", Q, nb, &dQ))) return rc;
+    rc = feasthip_orthonormalize_dev(h, m, dQ, rank_tol, rank);
+    if (rc) return rc;
+    FH_CHECK(hipMemcpy(Q, dQ, nb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Rayleigh-Ritz projection (a10)
+// ---------------------------------------------------------------------------------------
+static void fh_hermitize(std::vector<cplx>& G, int r) {
+    // _feast_hermitian_part!  src/core/feast_aux.jl:84-92
+    std::vector<cplx> out((size_t)r * r);
+    for (int j = 0; j < r; ++j)
+        for (int i = 0; i < r; ++i) {
+            cplx a = G[(size_t)j * r + i], b = cconj(G[(size_t)i * r + j]);
+            out[(size_t)j * r + i] = cmake(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+        }
+    G.swap(out);
+}
+
+extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* dQ, int bilinear, int hermitize,
+                                    void* Aq_host, void* Bq_host) {
+    int rc = fh_check_problem(h, r64);
+    if (rc) return rc;
+    if (!dQ || !Aq_host) { h->last_error = "project: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int r = (int)r64, ld = fh_pick_ld(r), N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "pj_Q", panel * sizeof(cplx), &p))) return rc;
+    cplx* Qp = (cplx*)p;
+    if ((rc = fh_get_buf(h, "pj_W", panel * sizeof(cplx), &p))) return rc;
+    cplx* W = (cplx*)p;
+    if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
+    cplx* gw = (cplx*)p;
+    if ((rc = fh_get_buf(h, "gram_G", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* G = (cplx*)p;
+    fh_launch_to_panel((const cplx*)dQ, N, N, r, Qp, ld, h->stream);
+    std::vector<cplx> one(ld, cmake(1, 0)), zero(ld, cmake(0, 0));
+    cplx *d1, *d0;
+    if ((rc = fh_upload_coefs(h, "pj_one", one, &d1))) return rc;
+    if ((rc = fh_upload_coefs(h, "pj_zero", zero, &d0))) return rc;
+    std::vector<cplx> Gh((size_t)ld * ld);
+    for (int which = 0; which < 2; ++which) {
+        cplx* out_host = (cplx*)(which == 0 ? Aq_host : Bq_host);
+        if (!out_host) continue;
+        std::vector<cplx> res((size_t)r * r);
+        if (which == 1 && fh_b_identity(h)) {
+            for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) res[(size_t)j * r + i] = cmake(i == j ? 1.0 : 0.0, 0.0);
+        } else {
+            fh_op_call oc;
+            oc.X = Qp; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
+            oc.coefA = which == 0 ? d1 : d0; oc.coefB = which == 0 ? d0 : d1;
+            oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+            oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+            fh_apply_operator(h, ld, oc);
+            fh_prof_begin(h, "gram");
+            fh_launch_gram(Qp, W, N, ld, bilinear, gw, G, h->stream);
+            fh_prof_end(h);
+            FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+            FH_CHECK(hipStreamSynchronize(h->stream));
+            for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) res[(size_t)j * r + i] = Gh[(size_t)j * ld + i];
+            if (hermitize && !bilinear) fh_hermitize(res, r);
+        }
+        memcpy(out_host, res.data(), res.size() * sizeof(cplx));
+    }
+    fh_prof_collect(h);
+    return 0;
+}
+
+extern "C" int feasthip_project(feasthip_handle h, int64_t r, const void* Q, int bilinear, int hermitize, void* Aq, void* Bq) {
+    int rc = fh_check_problem(h, r);
+    if (rc) return rc;
+    if (!Q) { h->last_error = "project: null Q"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    void* dQ;
+    if ((rc = fh_stage_in(h, "host_Q", Q, (size_t)fh_N(h) * r * sizeof(cplx), &dQ))) return rc;
+    return feasthip_project_dev(h, r, dQ, bilinear, hermitize, Aq, Bq);
+}
+
+// ---------------------------------------------------------------------------------------
+// Ritz back-transform + residual (a12, a13)
+// ---------------------------------------------------------------------------------------
+extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const void* dQ, const void* V_host,
+                                          const double* lambda_host, int64_t M, int normalize, int use_B, void* dX,
+                                          double* res_host) {
+    int rc = fh_check_problem(h, r64);
+    if (rc) return rc;
+    if (!dQ || !V_host || !lambda_host || !dX) { h->last_error = "ritz_residual: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    if (M < 0 || M > r64) { h->last_error = "ritz_residual: M out of range"; return FEASTHIP_ERROR_M0; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int r = (int)r64, ld = fh_pick_ld(r), N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "rz_Q", panel * sizeof(cplx), &p))) return rc;
+    cplx* Qp = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rz_X", panel * sizeof(cplx), &p))) return rc;
+    cplx* Xp = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rz_R", panel * sizeof(cplx), &p))) return rc;
+    cplx* Rp = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rz_V", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* dV = (cplx*)p;
+    const int nblk_op = fh_op_nblk(h), nblk_vec = fh_vec_nblk(N, ld);
+    if ((rc = fh_get_buf(h, "rz_part", (size_t)std::max(nblk_op, nblk_vec) * ld * sizeof(cplx), &p))) return rc;
+    cplx* part = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rz_dots", (size_t)ld * sizeof(cplx), &p))) return rc;
+    cplx* ddots = (cplx*)p;
+    // V padded to ld x ld
+    std::vector<cplx> Vp((size_t)ld * ld, cmake(0, 0));
+    const cplx* Vh = (const cplx*)V_host;
+    for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) Vp[(size_t)j * ld + i] = Vh[(size_t)j * r + i];
+    FH_CHECK(hipMemcpyAsync(dV, Vp.data(), Vp.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+    fh_launch_to_panel((const cplx*)dQ, N, N, r, Qp, ld, h->stream);
+    fh_prof_begin(h, "ritz");
+    fh_launch_small_matmul(Qp, dV, N, ld, Xp, h->stream);
+    fh_prof_end(h);
+    std::vector<cplx> dots(ld);
+    if (normalize && M > 0) {
+        // normalise the first M columns (src/dense/feast_dense.jl:301-305)
+        fh_launch_dot_cols(Xp, Xp, N, ld, part, ddots, h->stream);
+        FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        std::vector<cplx> sc(ld, cmake(1, 0));
+        for (int c = 0; c < (int)M; ++c) {
+            double n = std::sqrt(dots[c].x);
+            if (n > 0) sc[c] = cmake(1.0 / n, 0);
+        }
+        cplx* dsc;
+        if ((rc = fh_upload_coefs(h, "rz_scale", sc, &dsc))) return rc;
+        fh_launch_scale_cols(Xp, dsc, N, ld, h->stream);
+    }
+    fh_launch_from_panel(Xp, ld, N, r, (cplx*)dX, N, h->stream);
+    if (M > 0 && res_host) {
+        // R = A X - B X diag(lambda); res_j = ||R_j|| / max(|lambda_j|, 1)
+        std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
+        const bool lam_in_op = use_B || fh_b_identity(h);
+        for (int c = 0; c < r; ++c) cb[c] = lam_in_op ? cmake(-lambda_host[2 * c], -lambda_host[2 * c + 1]) : cmake(0, 0);
+        cplx *dca, *dcb;
+        if ((rc = fh_upload_coefs(h, "rz_coefA", ca, &dca))) return rc;
+        if ((rc = fh_upload_coefs(h, "rz_coefB", cb, &dcb))) return rc;
+        fh_op_call oc;
+        oc.X = Xp; oc.x_stride = 0; oc.Y = Rp; oc.y_stride = 0; oc.coefA = dca; oc.coefB = dcb;
+        oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+        oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+        fh_apply_operator(h, ld, oc);
+        if (!use_B && !fh_b_identity(h)) {
+            // RCI-style residual without B: R = A X - X diag(lambda)  (src/kernel/feast_kernel.jl:899-906)
+            std::vector<cplx> lam(ld, cmake(0, 0));
+            for (int c = 0; c < r; ++c) lam[c] = cmake(lambda_host[2 * c], lambda_host[2 * c + 1]);
+            cplx* dl;
+            if ((rc = fh_upload_coefs(h, "rz_lam", lam, &dl))) return rc;
+            fh_launch_axpy_cols(Rp, Xp, dl, N, ld, h->stream);   // R -= X diag(lam)
+        }
+        fh_launch_dot_cols(Rp, Rp, N, ld, part, ddots, h->stream);
+        FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        for (int c = 0; c < (int)M; ++c) {
+            double la = std::hypot(lambda_host[2 * c], lambda_host[2 * c + 1]);
+            res_host[c] = std::sqrt(dots[c].x) / std::max(la, 1.0);
+        }
+    }
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_prof_collect(h);
+    return 0;
+}
+
+extern "C" int feasthip_ritz_residual(feasthip_handle h, int64_t r, const void* Q, const void* V, const double* lambda,
+                                      int64_t M, int normalize, int use_B, void* X, double* res) {
+    int rc = fh_check_problem(h, r);
+    if (rc) return rc;
+    if (!Q || !X) { h->last_error = "ritz_residual: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const size_t nb = (size_t)fh_N(h) * r * sizeof(cplx);
+    void *dQ, *dX;
+    if ((rc = fh_stage_in(h, "host_Q", Q, nb, &dQ))) return rc;
+    if ((rc = fh_get_buf(h, "host_X", nb, &dX))) return rc;
+    rc = feasthip_ritz_residual_dev(h, r, dQ, V, lambda, M, normalize, use_B, dX, res);
+    if (rc) return rc;
+    FH_CHECK(hipMemcpy(X, dX, nb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// RCI seams: Y = A X / B X (jobs 30/40), Y = (zB - A)^{-1} X (jobs 10+11, linear_solver)
+// ---------------------------------------------------------------------------------------
+extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, const void* dX, void* dY) {
+    int rc = fh_check_problem(h, m64);
+    if (rc) return rc;
+    if (!dX || !dY || (which != 0 && which != 1)) { h->last_error = "matmul: bad argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "mm_X", panel * sizeof(cplx), &p))) return rc;
+    cplx* Xp = (cplx*)p;
+    if ((rc = fh_get_buf(h, "mm_Y", panel * sizeof(cplx), &p))) return rc;
+    cplx* Yp = (cplx*)p;
+    fh_launch_to_panel((const cplx*)dX, N, N, m, Xp, ld, h->stream);
+    std::vector<cplx> ca(ld, cmake(which == 0 ? 1 : 0, 0)), cb(ld, cmake(which == 1 ? 1 : 0, 0));
+    cplx *dca, *dcb;
+    if ((rc = fh_upload_coefs(h, "mm_coefA", ca, &dca))) return rc;
+    if ((rc = fh_upload_coefs(h, "mm_coefB", cb, &dcb))) return rc;
+    fh_op_call oc;
+    oc.X = Xp; oc.x_stride = 0; oc.Y = Yp; oc.y_stride = 0; oc.coefA = dca; oc.coefB = dcb;
+    oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+    oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+    fh_apply_operator(h, ld, oc);
+    fh_launch_from_panel(Yp, ld, N, m, (cplx*)dY, N, h->stream);
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_prof_collect(h);
+    return 0;
+}
+
+extern "C" int feasthip_matmul(feasthip_handle h, int which, int64_t m, const void* X, void* Y) {
+    int rc = fh_check_problem(h, m);
+    if (rc) return rc;
+    if (!X || !Y) { h->last_error = "matmul: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const size_t nb = (size_t)fh_N(h) * m * sizeof(cplx);
+    void *dX, *dY;
+    if ((rc = fh_stage_in(h, "host_Q", X, nb, &dX))) return rc;
+    if ((rc = fh_get_buf(h, "host_X", nb, &dY))) return rc;
+    rc = feasthip_matmul_dev(h, which, m, dX, dY);
+    if (rc) return rc;
+    FH_CHECK(hipMemcpy(Y, dY, nb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double z_im, int64_t m64, const void* dX,
+                                          void* dY, feasthip_stats* stats) {
+    int rc = fh_check_problem(h, m64);
+    if (rc) return rc;
+    if (!dX || !dY) { h->last_error = "shifted_solve: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "ss_rhs", panel * sizeof(cplx), &p))) return rc;
+    cplx* Rhs = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ss_Y", panel * sizeof(cplx), &p))) return rc;
+    cplx* Y = (cplx*)p;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    fh_launch_to_panel((const cplx*)dX, N, N, m, Rhs, ld, h->stream);
+    std::vector<cplx> z(1, cmake(z_re, z_im));
+    std::vector<int> status(1, 0);
+    if (h->solver == FEASTHIP_SOLVER_LU) {
+        if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix"; return FEASTHIP_ERROR_FPM; }
+        int64_t nfact = 0;
+        // one-off factorisation, not cached (node index -1)
+        rc = fh_dense_lu_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
+        if (rc) return rc;
+        if (stats) stats->factorizations = nfact;
+    } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB) {
+        FH_CHECK(hipMemsetAsync(Y, 0, panel * sizeof(cplx), h->stream));
+        fh_solve_result sr;
+        rc = fh_bicgstab(h, ld, m, 1, z, Rhs, Y, panel, sr);
+        if (rc) return rc;
+        status = sr.status;
+        if (stats) { stats->krylov_iterations = sr.iters_sum; stats->spmm_calls = sr.op_calls; stats->max_rel_residual = sr.max_rel_res; }
+    } else {
+        h->last_error = "solver GMRES is not implemented on the device yet; use BICGSTAB";
+        return FEASTHIP_ERROR_FPM;
+    }
+    fh_launch_from_panel(Y, ld, N, m, (cplx*)dY, N, h->stream);
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_prof_collect(h);
+    return status[0];
+}
+
+extern "C" int feasthip_shifted_solve(feasthip_handle h, double z_re, double z_im, int64_t m, const void* X, void* Y,
+                                      feasthip_stats* stats) {
+    int rc = fh_check_problem(h, m);
+    if (rc) return rc;
+    if (!X || !Y) { h->last_error = "shifted_solve: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const size_t nb = (size_t)fh_N(h) * m * sizeof(cplx);
+    void *dX, *dY;
+    if ((rc = fh_stage_in(h, "host_Q", X, nb, &dX))) return rc;
+    if ((rc = fh_get_buf(h, "host_X", nb, &dY))) return rc;
+    rc = feasthip_shifted_solve_dev(h, z_re, z_im, m, dX, dY, stats);
+    if (rc != 0 && rc != FEASTHIP_ERROR_NO_CONVERGENCE) return rc;
+    FH_CHECK(hipMemcpy(Y, dY, nb, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
+// measurement support
+// ---------------------------------------------------------------------------------------
+extern "C" int feasthip_profile_enable(feasthip_handle h, int enable) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    h->profiling = enable ? 1 : 0;
+    return 0;
+}
+extern "C" int feasthip_profile_reset(feasthip_handle h) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    fh_prof_collect(h);
+    h->prof.clear();
+    return 0;
+}
+extern "C" int feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms, int64_t* launches) {
+    if (!h || !kernel_class) return FEASTHIP_ERROR_INTERNAL;
+    fh_prof_collect(h);
+    auto it = h->prof.find(kernel_class);
+    auto is = h->prof.find(std::string(kernel_class) + "#sampled");
+    int64_t n = it == h->prof.end() ? 0 : it->second.launches;
+    double avg = 0.0;
+    if (is != h->prof.end() && is->second.launches > 0) avg = is->second.total_ms / (double)is->second.launches;
+    if (total_ms) *total_ms = avg * (double)n;   // estimated total = sampled average x launches
+    if (launches) *launches = n;
+    return 0;
+}

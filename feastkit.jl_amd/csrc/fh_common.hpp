@@ -1,0 +1,143 @@
+// fh_common.hpp -- shared types for libfeasthip (gfx950 / CDNA4 only).
+//
+// Internal block-vector layout ("panel"): an N x m complex block is stored ROW-MAJOR with a
+// padded row length ld in {16,32,64} c128 elements, so one row of a 64-column block is one
+// contiguous 1 KiB line = one wave-wide 16 B/lane access.  Lane <-> column, so every
+// per-column scalar of the batched Krylov solver (alpha_c, omega_c, ...) lives in the lane
+// that owns column c, and a gathered SpMM row read is a single coalesced wave access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+struct __attribute__((aligned(16))) cplx { double x, y; };
+
+__host__ __device__ inline cplx cmake(double a, double b) { cplx r; r.x = a; r.y = b; return r; }
+__host__ __device__ inline cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cplx cmul(cplx a, cplx b) { return cmake(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ inline cplx cmulc(cplx a, cplx b) { /* conj(a)*b */ return cmake(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }
+__host__ __device__ inline cplx cscale(cplx a, double s) { return cmake(a.x * s, a.y * s); }
+__host__ __device__ inline cplx cconj(cplx a) { return cmake(a.x, -a.y); }
+__host__ __device__ inline double cabs2(cplx a) { return a.x * a.x + a.y * a.y; }
+__host__ __device__ inline cplx cdiv(cplx a, cplx b) {
+    double d = b.x * b.x + b.y * b.y;
+    return cmake((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+// acc += a*b
+__host__ __device__ inline void cfma(cplx& acc, cplx a, cplx b) {
+    acc.x += a.x * b.x - a.y * b.y;
+    acc.y += a.x * b.y + a.y * b.x;
+}
+// matrix value (real or complex) times complex
+__host__ __device__ inline cplx vmul(double a, cplx b) { return cmake(a * b.x, a * b.y); }
+__host__ __device__ inline cplx vmul(cplx a, cplx b) { return cmul(a, b); }
+
+#define FH_MAX_LD 64
+
+#define FH_CHECK(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            h->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);              \
+            return (_e == hipErrorOutOfMemory) ? 6 : 7;                                     \
+        }                                                                                   \
+    } while (0)
+
+// ---- profiling of kernel classes with HIP events on the handle's stream -----------------
+struct fh_prof_class {
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct fh_event_pair {
+    hipEvent_t a, b;
+    std::string cls;
+};
+
+// ---- device CSR (union pattern of A and B) ---------------------------------------------
+struct fh_csr {
+    int64_t N = 0, nnz = 0;
+    int is_complex = 0;      // values are double (0) or cplx (1)
+    int b_identity = 0;      // no B values: B = I
+    int* rowptr = nullptr;   // N+1
+    int* col = nullptr;      // nnz
+    void* aval = nullptr;    // nnz x (double|cplx), A on the union pattern
+    void* bval = nullptr;    // nnz x (double|cplx), B on the union pattern (null if identity)
+};
+
+struct fh_dense {
+    int64_t N = 0;
+    int is_complex = 0;
+    int b_identity = 0;
+    void* A = nullptr;       // N x N column-major, double or cplx
+    void* B = nullptr;
+};
+
+// Per-(node,column) Krylov scalars, struct of arrays; each array is [nodes][ld].
+struct fh_krylov_scalars {
+    cplx* rho = nullptr;
+    cplx* alpha = nullptr;
+    cplx* omega = nullptr;
+    cplx* beta = nullptr;
+    double* r0norm = nullptr;
+    double* target = nullptr;
+    double* rnorm = nullptr;
+    int* active = nullptr;    // 1 while the column is still iterating
+    int* iters = nullptr;     // iterations performed by the column
+    int* status = nullptr;    // 0 converged, 5 not converged, 8 breakdown
+    int* node_active = nullptr;  // [nodes]: number of active columns of the node
+};
+
+struct feasthip_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // problem
+    int kind = 0;  // 0 none, 1 dense, 2 sparse
+    fh_csr csr;
+    fh_dense dense;
+
+    // contour
+    std::vector<cplx> zne, wne;
+    double weight_scale = 2.0;
+    int node_first = 0, node_count = 0;
+
+    // solver options
+    int solver = 1;
+    double rtol = 1e-12, atol = 0.0;
+    int maxit = 500, restart = 30, factor_precision = 64, cache_factors = 1;
+
+    // workspace (grown lazily)
+    std::map<std::string, std::pair<void*, size_t>> bufs;
+
+    // dense LU cache: per local node factors + pivots
+    std::vector<void*> lu_factors;
+    std::vector<int*> lu_pivots;
+    std::vector<int> lu_valid;
+    std::vector<cplx> lu_z;
+
+    // profiling
+    int profiling = 0;
+    std::map<std::string, fh_prof_class> prof;
+    std::vector<fh_event_pair> pending_events;
+};
+
+// workspace helper: returns a device buffer of at least `bytes`, reallocating if needed
+int fh_get_buf(feasthip_ctx* h, const char* name, size_t bytes, void** out);
+void fh_free_bufs(feasthip_ctx* h);
+
+// profiling helpers
+void fh_prof_begin(feasthip_ctx* h, const char* cls);
+void fh_prof_end(feasthip_ctx* h);
+void fh_prof_collect(feasthip_ctx* h);
+
+static inline int fh_pick_ld(int64_t m) {
+    if (m <= 16) return 16;
+    if (m <= 32) return 32;
+    return 64;
+}

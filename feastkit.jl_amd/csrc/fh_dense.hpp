@@ -1,0 +1,30 @@
+// fh_dense.hpp -- dense shifted systems: operator application on panels and the batched
+// complex LU (form z B - A, factor with partial pivoting, solve) for the FEAST contour sweep.
+#pragma once
+#include "fh_common.hpp"
+#include <vector>
+
+struct fh_dense_op_args {
+    const void* A; const void* B;   // N x N column-major, double or cplx; B may be null (identity)
+    int N; int is_complex; int nodes;
+    const cplx* X; size_t x_node_stride;
+    cplx* Y; size_t y_node_stride;
+    const cplx* coefA; const cplx* coefB;
+    const cplx* Bvec; size_t b_node_stride;
+    const cplx* U; size_t u_node_stride;
+    int dot_mode; cplx* partial1; cplx* partial2;
+    const int* node_active;
+};
+int fh_dense_op_nblk(int N);
+void fh_launch_dense_op(const fh_dense_op_args& a, int ld, int nblk, hipStream_t st);
+
+// R -= X diag(lam)
+void fh_launch_axpy_cols(cplx* R, const cplx* X, const cplx* lam, int N, int ld, hipStream_t st);
+
+// Factor (cached per local node when h->cache_factors) and solve all local nodes:
+//   Y[e] = (z_e B - A)^{-1} RHS     RHS: one shared panel; Y: node-strided panels
+int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
+                            cplx* Y, size_t stride, std::vector<int>& status, int64_t* nfact);
+// one-off (uncached) solve for a single shift
+int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status,
+                             int64_t* nfact);

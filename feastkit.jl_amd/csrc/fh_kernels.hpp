@@ -1,0 +1,83 @@
+// fh_kernels.hpp -- argument structs and launcher prototypes shared by the .hip units.
+#pragma once
+#include "fh_common.hpp"
+
+// ---- sparse operator -------------------------------------------------------------------
+struct fh_spmm_args {
+    const int* rowptr; const int* col; const void* aval; const void* bval;
+    int N; int nodes;
+    const cplx* X; size_t x_node_stride;      // element stride between nodes (0 = shared)
+    cplx* Y; size_t y_node_stride;
+    const cplx* coefA; const cplx* coefB;     // [nodes][LD] per-column coefficients
+    const cplx* Bvec; size_t b_node_stride;   // non-null: Y = Bvec - S X
+    const cplx* U; size_t u_node_stride;      // dot_mode 1: <U, Y>
+    int dot_mode;
+    cplx* partial1; cplx* partial2;           // [nodes][nblk][LD]
+    const int* node_active;                   // may be null
+};
+void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st);
+
+// ---- BiCGStab vector kernels -----------------------------------------------------------
+struct fh_vec_args {
+    int N;
+    size_t node_stride;
+    cplx *X, *R, *Rhat, *P, *V, *S, *T;
+    const cplx* Q;             // init guess source (shared by all nodes)
+    const double* lambda;      // [LD] Ritz values or null
+    const cplx* znode;         // [nodes]
+    fh_krylov_scalars s;
+    cplx* partial1; cplx* partial2;
+};
+struct fh_fin_args {
+    fh_krylov_scalars s;
+    const cplx* partial1; const cplx* partial2;
+    int nblk; int m;
+    double rtol, atol;
+};
+void fh_launch_init_guess(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_copy_r(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_p_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st);
+
+// ---- block (panel) operations ------------------------------------------------------------
+// column-major (N x m, leading dim lds) <-> row-major panel (N x ld), zero padded
+void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
+void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int64_t ldd, hipStream_t st);
+// real column-major source -> complex panel
+void fh_launch_to_panel_real(const double* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
+// dst = sum_e w[e] * X[e]
+void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld,
+                          cplx* dst, hipStream_t st);
+// G (ld x ld, column-major, ldg = ld) = X^H Y (bilinear=0) or X^T Y (bilinear=1); f64 MFMA.
+// work: at least fh_gram_work_elems(ld) cplx.
+size_t fh_gram_work_elems(int ld);
+void fh_launch_gram(const cplx* X, const cplx* Y, int N, int ld, int bilinear, cplx* work, cplx* G,
+                    hipStream_t st);
+// per-column dots: out[c] = <U[:,c], V[:,c]>; work: nblk*ld cplx
+int fh_vec_nblk(int N, int ld);
+void fh_launch_dot_cols(const cplx* U, const cplx* V, int N, int ld, cplx* work, cplx* out, hipStream_t st);
+// X[:,c] *= s[c]
+void fh_launch_scale_cols(cplx* X, const cplx* s, int N, int ld, hipStream_t st);
+// Xout = Q * V   (V: ld x ld column-major on device, zero padded)
+void fh_launch_small_matmul(const cplx* Q, const cplx* V, int N, int ld, cplx* Xout, hipStream_t st);
+// dst[:,k] = src[:,perm[k]] for k < count else 0
+void fh_launch_gather_cols(const cplx* src, const int* perm, int count, int N, int ld, cplx* dst, hipStream_t st);
+
+// column-pivoted modified Gram-Schmidt with re-orthogonalisation, fully on device.
+// state: int[4 + ld] = {k (steps done), rank, done, pivot, perm[ld]}; dstate: double[2+ld] = {R11, thr, norm2[ld]}
+struct fh_mgs_args {
+    cplx* X; int N; int ld; int m;
+    int* istate; double* dstate; cplx* coef;   // coef[ld]
+    cplx* work;                                // nblk*ld partials
+    double rank_tol;
+};
+void fh_mgs_run(const fh_mgs_args& a, hipStream_t st);
+
+// dense kernels ---------------------------------------------------------------------------
+struct fh_dense;

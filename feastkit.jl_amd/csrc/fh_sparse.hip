@@ -1,0 +1,411 @@
+// fh_sparse.hip -- batched sparse shifted solves for the FEAST contour sweep (gfx950).
+//
+// Replaces, for all RHS columns and all local quadrature nodes at once:
+//   SparseShiftedOperator.mul!            src/sparse/feast_sparse.jl:20-27   (2 SpMV + 2 axpy)
+//   solve_shifted_iterative!              src/sparse/feast_sparse.jl:164-203 (per-column GMRES)
+//   Krylov.bicgstab matrix-free solver    src/interfaces/feast_matfree.jl:716-718
+//
+// Data layout: block vectors are row-major N x LD c128 ("panels", fh_common.hpp); the
+// node batch is the y dimension of every launch.  The operator is never materialised per
+// node: S_c = coefB[c]*B + coefA[c]*A is formed on the fly from the real (or complex) CSR
+// values of A and B on their union pattern, with a per-COLUMN complex coefficient pair so
+// the same kernel serves (z_e B - A)X, A X, B X and the residual A X - B X diag(lambda).
+#include "fh_common.hpp"
+#include "fh_kernels.hpp"
+
+#define FH_BLOCK 256
+
+// XCD-aware virtual block id: blocks b, b+8, ... share an XCD (round-robin dispatch), so
+// give each XCD one contiguous chunk of the row range; neighbouring stencil rows then hit
+// the same L2.  Bijective when gridDim.x % 8 == 0 (the launcher guarantees it).
+__device__ __forceinline__ int fh_virtual_block(int b, int nb) {
+    return (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+template <int LD>
+__device__ __forceinline__ void fh_block_reduce_cols(cplx v, cplx* red, cplx* out) {
+    // 256 threads; thread t owns column t % LD.  Sum the 256/LD partials of each column.
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    if (t < LD) {
+        cplx s = red[t];
+#pragma unroll
+        for (int k = 1; k < FH_BLOCK / LD; ++k) s = cadd(s, red[t + k * LD]);
+        out[t] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------
+// SpMM:  Y[node] = (Bvec -) (coefB*B + coefA*A) X[node]      with optional fused dots
+//   dot_mode 0: none
+//            1: partial1 = <U, Y>                 (BiCGStab sigma = <rhat, v>)
+//            2: partial1 = <Y, Xown>, partial2 = <Y, Y>   (omega = <t,s>/<t,t>)
+//            3: partial2 = <Y, Y>                 (residual norms)
+// Mapping: a wave covers 64/LD rows x LD columns; each block owns a contiguous row chunk.
+// ------------------------------------------------------------------------------------
+template <typename VT, int LD, bool BIDENT>
+__global__ __launch_bounds__(FH_BLOCK) void k_spmm(fh_spmm_args a) {
+    const int node = blockIdx.y;
+    if (a.node_active && a.node_active[node] == 0) {
+        // still have to publish zero partials so the finalize kernels read defined data
+        if (a.dot_mode != 0 && threadIdx.x < LD) {
+            size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD + threadIdx.x;
+            if (a.partial1) a.partial1[o] = cmake(0, 0);
+            if (a.partial2) a.partial2[o] = cmake(0, 0);
+        }
+        return;
+    }
+    constexpr int RPW = 64 / LD;             // rows per wave pass
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane % LD;
+    const int rsub = lane / LD;
+    const int vb = fh_virtual_block(blockIdx.x, gridDim.x);
+    const int rows_per_block = (a.N + gridDim.x - 1) / gridDim.x;
+    const int row_begin = vb * rows_per_block;
+    const int row_end = min(a.N, row_begin + rows_per_block);
+
+    const cplx* X = a.X + (size_t)node * a.x_node_stride;
+    cplx* Y = a.Y + (size_t)node * a.y_node_stride;
+    const cplx* Bv = a.Bvec ? a.Bvec + (size_t)node * a.b_node_stride : nullptr;
+    const cplx* U = a.U ? a.U + (size_t)node * a.u_node_stride : nullptr;
+    const cplx ca = a.coefA[node * LD + c];
+    const cplx cb = a.coefB[node * LD + c];
+    const VT* aval = (const VT*)a.aval;
+    const VT* bval = (const VT*)a.bval;
+
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    for (int i = row_begin + wave * RPW + rsub; i < row_end; i += (FH_BLOCK / 64) * RPW) {
+        const int k0 = a.rowptr[i], k1 = a.rowptr[i + 1];
+        cplx acc = cmake(0, 0);
+        cplx xown = cmake(0, 0);
+        if (BIDENT || a.dot_mode == 2) xown = X[(size_t)i * LD + c];
+        if (BIDENT) acc = cmul(cb, xown);        // B = I contributes cb * x_i
+        for (int k = k0; k < k1; ++k) {
+            const int j = a.col[k];
+            const cplx x = X[(size_t)j * LD + c];
+            cplx s = vmul(aval[k], ca);
+            if (!BIDENT) s = cadd(s, vmul(bval[k], cb));
+            cfma(acc, s, x);
+        }
+        if (Bv) acc = csub(Bv[(size_t)i * LD + c], acc);
+        Y[(size_t)i * LD + c] = acc;
+        if (a.dot_mode == 1) {
+            cplx u = U[(size_t)i * LD + c];
+            d1 = cadd(d1, cmulc(u, acc));
+        } else if (a.dot_mode == 2) {
+            d1 = cadd(d1, cmulc(acc, xown));
+            d2.x += cabs2(acc);
+        } else if (a.dot_mode == 3) {
+            d2.x += cabs2(acc);
+        }
+    }
+    if (a.dot_mode != 0) {
+        __shared__ cplx red[FH_BLOCK];
+        size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+        if (a.dot_mode == 1 || a.dot_mode == 2) fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+        if (a.dot_mode == 2 || a.dot_mode == 3) fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+    }
+}
+
+template <typename VT, int LD>
+static void launch_spmm_ld(const fh_spmm_args& a, bool bident, int nblk, hipStream_t st) {
+    dim3 grid(nblk, a.nodes), block(FH_BLOCK);
+    if (bident)
+        hipLaunchKernelGGL((k_spmm<VT, LD, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_spmm<VT, LD, false>), grid, block, 0, st, a);
+}
+
+void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st) {
+    if (is_complex) {
+        if (ld == 16) launch_spmm_ld<cplx, 16>(a, bident, nblk, st);
+        else if (ld == 32) launch_spmm_ld<cplx, 32>(a, bident, nblk, st);
+        else launch_spmm_ld<cplx, 64>(a, bident, nblk, st);
+    } else {
+        if (ld == 16) launch_spmm_ld<double, 16>(a, bident, nblk, st);
+        else if (ld == 32) launch_spmm_ld<double, 32>(a, bident, nblk, st);
+        else launch_spmm_ld<double, 64>(a, bident, nblk, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// BiCGStab vector kernels.  Flat element index over the N*LD panel, grid-stride with a
+// stride that is a multiple of LD so a thread always sees the same column.
+// ------------------------------------------------------------------------------------
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_init_guess(fh_vec_args a) {
+    // X0[i,c] = Q[i,c] / (z_node - lambda_c)   (lambda == nullptr -> zero guess)
+    const int node = blockIdx.y;
+    const size_t total = (size_t)a.N * LD;
+    const int c = threadIdx.x % LD;
+    cplx* X = a.X + (size_t)node * a.node_stride;
+    cplx f = cmake(0, 0);
+    if (a.lambda) {
+        cplx z = a.znode[node];
+        f = cdiv(cmake(1, 0), cmake(z.x - a.lambda[c], z.y));
+    }
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
+        X[e] = a.lambda ? cmul(a.Q[e], f) : cmake(0, 0);
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_copy_r(fh_vec_args a) {
+    // Rhat = R, P = R
+    const int node = blockIdx.y;
+    const size_t total = (size_t)a.N * LD;
+    const cplx* R = a.R + (size_t)node * a.node_stride;
+    cplx* Rh = a.Rhat + (size_t)node * a.node_stride;
+    cplx* P = a.P + (size_t)node * a.node_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx r = R[e];
+        Rh[e] = r;
+        P[e] = r;
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_p_update(fh_vec_args a) {
+    // P = R + beta (P - omega V)
+    const int node = blockIdx.y;
+    if (a.s.node_active[node] == 0) return;
+    const size_t total = (size_t)a.N * LD;
+    const int c = threadIdx.x % LD;
+    if (!a.s.active[node * LD + c]) return;
+    const cplx beta = a.s.beta[node * LD + c], omega = a.s.omega[node * LD + c];
+    const cplx* R = a.R + (size_t)node * a.node_stride;
+    const cplx* V = a.V + (size_t)node * a.node_stride;
+    cplx* P = a.P + (size_t)node * a.node_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx t = csub(P[e], cmul(omega, V[e]));
+        P[e] = cadd(R[e], cmul(beta, t));
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_s_update(fh_vec_args a) {
+    // S = R - alpha V
+    const int node = blockIdx.y;
+    if (a.s.node_active[node] == 0) return;
+    const size_t total = (size_t)a.N * LD;
+    const int c = threadIdx.x % LD;
+    if (!a.s.active[node * LD + c]) return;
+    const cplx alpha = a.s.alpha[node * LD + c];
+    const cplx* R = a.R + (size_t)node * a.node_stride;
+    const cplx* V = a.V + (size_t)node * a.node_stride;
+    cplx* S = a.S + (size_t)node * a.node_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
+        S[e] = csub(R[e], cmul(alpha, V[e]));
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_xr_update(fh_vec_args a) {
+    // X += alpha P + omega S ; R = S - omega T ; partial1 = <Rhat, R>, partial2 = <R, R>
+    const int node = blockIdx.y;
+    const int c = threadIdx.x % LD;
+    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
+    if (on) {
+        const size_t total = (size_t)a.N * LD;
+        const cplx alpha = a.s.alpha[node * LD + c], omega = a.s.omega[node * LD + c];
+        const cplx* P = a.P + (size_t)node * a.node_stride;
+        const cplx* S = a.S + (size_t)node * a.node_stride;
+        const cplx* T = a.T + (size_t)node * a.node_stride;
+        const cplx* Rh = a.Rhat + (size_t)node * a.node_stride;
+        cplx* X = a.X + (size_t)node * a.node_stride;
+        cplx* R = a.R + (size_t)node * a.node_stride;
+        for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+            cplx s = S[e];
+            cplx x = X[e];
+            cfma(x, alpha, P[e]);
+            cfma(x, omega, s);
+            X[e] = x;
+            cplx r = csub(s, cmul(omega, T[e]));
+            R[e] = r;
+            d1 = cadd(d1, cmulc(Rh[e], r));
+            d2.x += cabs2(r);
+        }
+    }
+    __shared__ cplx red[FH_BLOCK];
+    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+}
+
+// ---- finalize kernels: one block per node, reduce the per-block partials ---------------
+template <int LD>
+__device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, int nblk, cplx* red) {
+    const int t = threadIdx.x;
+    const int c = t % LD, g = t / LD;
+    constexpr int G = FH_BLOCK / LD;
+    cplx s = cmake(0, 0);
+    const cplx* p = partial + (size_t)node * nblk * LD;
+    for (int b = g; b < nblk; b += G) s = cadd(s, p[(size_t)b * LD + c]);
+    red[t] = s;
+    __syncthreads();
+    cplx tot = cmake(0, 0);
+    if (t < LD) {
+        tot = red[t];
+        for (int k = 1; k < G; ++k) tot = cadd(tot, red[t + k * LD]);
+    }
+    __syncthreads();
+    return tot;  // valid for t < LD
+}
+
+__device__ __forceinline__ bool fh_finite(cplx a) { return isfinite(a.x) && isfinite(a.y); }
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_fin_init(fh_fin_args a) {
+    // after R = b - S X0 with partial2 = <R,R>: set r0norm, target, rho = <rhat,r> = ||r||^2
+    __shared__ cplx red[FH_BLOCK];
+    __shared__ int cnt;
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (t == 0) cnt = 0;
+    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        double rn = sqrt(rr.x);
+        a.s.r0norm[i] = rn;
+        a.s.rnorm[i] = rn;
+        double target = a.atol + a.rtol * rn;
+        a.s.target[i] = target;
+        a.s.rho[i] = cmake(rr.x, 0);
+        a.s.alpha[i] = cmake(1, 0);
+        a.s.omega[i] = cmake(1, 0);
+        a.s.beta[i] = cmake(0, 0);
+        a.s.iters[i] = 0;
+        int act = (t < a.m) && (rn > target) && isfinite(rn);
+        a.s.active[i] = act;
+        a.s.status[i] = (t < a.m && !isfinite(rn)) ? 8 : 0;
+        if (act) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (t == 0) a.s.node_active[node] = cnt;
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_fin_alpha(fh_fin_args a) {
+    // alpha = rho / <rhat, v>
+    __shared__ cplx red[FH_BLOCK];
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (a.s.node_active[node] == 0) return;
+    cplx sigma = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        if (a.s.active[i]) {
+            cplx al = cdiv(a.s.rho[i], sigma);
+            if (cabs2(sigma) == 0.0 || !fh_finite(al)) {
+                a.s.active[i] = 0;
+                a.s.status[i] = 8;   // breakdown
+                al = cmake(0, 0);
+            }
+            a.s.alpha[i] = al;
+        }
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_fin_omega(fh_fin_args a) {
+    // omega = <t,s> / <t,t>
+    __shared__ cplx red[FH_BLOCK];
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (a.s.node_active[node] == 0) return;
+    cplx ts = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
+    cplx tt = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        if (a.s.active[i]) {
+            cplx om = cmake(ts.x / tt.x, ts.y / tt.x);
+            if (tt.x == 0.0 || !fh_finite(om)) om = cmake(0, 0);  // s == 0: x += alpha p is exact
+            a.s.omega[i] = om;
+        }
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_fin_rho(fh_fin_args a) {
+    // rho_new = <rhat, r>, beta = (rho_new/rho)(alpha/omega); convergence bookkeeping
+    __shared__ cplx red[FH_BLOCK];
+    __shared__ int cnt;
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (a.s.node_active[node] == 0) return;
+    if (t == 0) cnt = 0;
+    cplx rho_new = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
+    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        if (a.s.active[i]) {
+            double rn = sqrt(rr.x);
+            a.s.rnorm[i] = rn;
+            a.s.iters[i] += 1;
+            int act = 1;
+            if (!(rn > a.s.target[i])) { act = 0; a.s.status[i] = 0; }
+            else if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
+            else {
+                cplx om = a.s.omega[i];
+                cplx beta = cmul(cdiv(rho_new, a.s.rho[i]), cdiv(a.s.alpha[i], om));
+                if (cabs2(om) == 0.0 || cabs2(a.s.rho[i]) == 0.0 || !fh_finite(beta)) {
+                    act = 0; a.s.status[i] = 8;
+                } else {
+                    a.s.beta[i] = beta;
+                    a.s.rho[i] = rho_new;
+                }
+            }
+            a.s.active[i] = act;
+            if (act) atomicAdd(&cnt, 1);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        a.s.node_active[node] = cnt;
+    }
+}
+
+// total number of active columns over all nodes -> *out (one block)
+__global__ void k_count_active(const int* node_active, int nodes, int* out) {
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < nodes; ++i) s += node_active[i];
+        *out = s;
+    }
+}
+
+#define FH_DISPATCH_LD(ld, KERNEL, grid, st, args)                                         \
+    do {                                                                                    \
+        if ((ld) == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(FH_BLOCK), 0, st, args); \
+        else if ((ld) == 32) hipLaunchKernelGGL((KERNEL<32>), grid, dim3(FH_BLOCK), 0, st, args); \
+        else hipLaunchKernelGGL((KERNEL<64>), grid, dim3(FH_BLOCK), 0, st, args);           \
+    } while (0)
+
+void fh_launch_init_guess(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_init_guess, dim3(nblk, nodes), st, a);
+}
+void fh_launch_copy_r(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_copy_r, dim3(nblk, nodes), st, a);
+}
+void fh_launch_p_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_p_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_s_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_xr_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_fin_init, dim3(nodes), st, a);
+}
+void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_fin_alpha, dim3(nodes), st, a);
+}
+void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_fin_omega, dim3(nodes), st, a);
+}
+void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_fin_rho, dim3(nodes), st, a);
+}
+void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_count_active, dim3(1), dim3(64), 0, st, node_active, nodes, out);
+}

@@ -1,0 +1,232 @@
+"""HipEngine: the device side of the ``:hip`` backend -- a thin object over the C ABI
+(include/feasthip.h).  PyTorch is used only as plumbing: device allocations, the current
+HIP stream and ``torch.distributed`` (RCCL) for the per-loop all-reduce of Q_proj.
+
+Block vectors live on the device as COLUMN-MAJOR N x m complex128, i.e. a contiguous
+torch tensor of shape (m, N) -- the layout of the reference's Julia ``Matrix{ComplexF64}``.
+
+There is no CPU fallback: constructing a HipEngine without libfeasthip.so or without a
+visible MI355X raises ``FeastHipUnavailable``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FeastHipStats, FeastHipUnavailable
+from .types import FeastHipError
+
+SOLVER_LU, SOLVER_BICGSTAB, SOLVER_GMRES = 0, 1, 2
+_SOLVER_CODES = {"direct": SOLVER_LU, "lu": SOLVER_LU, "bicgstab": SOLVER_BICGSTAB,
+                 "iterative": SOLVER_BICGSTAB, "gmres": SOLVER_GMRES}
+MAX_BLOCK = 64   # FH_MAX_LD: widest panel the kernels take in one call
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class HipEngine:
+    def __init__(self, device_index: int = 0):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load_library()
+        if not torch.cuda.is_available():
+            raise FeastHipUnavailable("no HIP device visible (torch.cuda.is_available() is False); "
+                                      "feastkit.jl_amd has no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        h = C.c_void_p()
+        rc = self.lib.feasthip_create(C.byref(h), device_index)
+        if rc != 0 or not h:
+            raise FeastHipUnavailable(f"feasthip_create(device={device_index}) failed with code {rc}")
+        self.h = h
+        self._chk(self.lib.feasthip_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self.N = 0
+        self.b_identity = True
+        self.last_stats = {}
+
+    # -- lifecycle ----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.feasthip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, ok=(0,)):
+        if rc not in ok:
+            msg = self.lib.feasthip_last_error(self.h)
+            raise FeastHipError(rc, msg.decode() if msg else "")
+        return rc
+
+    # -- problem ------------------------------------------------------------------
+    def set_problem(self, A, B=None):
+        import scipy.sparse as sp
+        if sp.issparse(A):
+            self._set_csr(A, B)
+        else:
+            self._set_dense(np.asarray(A), None if B is None else np.asarray(B))
+
+    def _set_dense(self, A, B):
+        N = A.shape[0]
+        if A.ndim != 2 or A.shape[1] != N:
+            raise ValueError("Matrix A must be square")
+        if B is not None and B.shape != (N, N):
+            raise ValueError("Matrix B must match size of A")
+        cplx = np.iscomplexobj(A) or (B is not None and np.iscomplexobj(B))
+        dt = np.complex128 if cplx else np.float64
+        Af = np.asfortranarray(A, dtype=dt)
+        Bf = None if B is None else np.asfortranarray(B, dtype=dt)
+        self._chk(self.lib.feasthip_set_dense(self.h, N, int(cplx), _np_ptr(Af), N, _np_ptr(Bf), N))
+        self.N, self.b_identity = N, B is None
+
+    def _set_csr(self, A, B):
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A)
+        N = A.shape[0]
+        if A.shape[1] != N:
+            raise ValueError("Matrix A must be square")
+        cplx = np.iscomplexobj(A.data) or (B is not None and np.iscomplexobj(sp.csr_matrix(B).data))
+        dt = np.complex128 if cplx else np.float64
+        pa, ia, va = A.indptr.astype(np.int64), A.indices.astype(np.int64), np.ascontiguousarray(A.data, dtype=dt)
+        if B is not None:
+            B = sp.csr_matrix(B)
+            if B.shape != A.shape:
+                raise ValueError("Matrix B must match size of A")
+            pb, ib, vb = B.indptr.astype(np.int64), B.indices.astype(np.int64), np.ascontiguousarray(B.data, dtype=dt)
+            nb = len(vb)
+        else:
+            pb = ib = vb = None
+            nb = 0
+        self._chk(self.lib.feasthip_set_csr(self.h, N, int(cplx), 0, 0, len(va), _np_ptr(pa), _np_ptr(ia), _np_ptr(va),
+                                            nb, _np_ptr(pb), _np_ptr(ib), _np_ptr(vb)))
+        self.N, self.b_identity = N, B is None
+
+    def set_contour(self, Zne, Wne, weight_scale):
+        z = np.ascontiguousarray(Zne, dtype=np.complex128)
+        w = np.ascontiguousarray(Wne, dtype=np.complex128)
+        self._chk(self.lib.feasthip_set_contour(self.h, len(z), _np_ptr(z), _np_ptr(w), float(weight_scale)))
+        self.ne = len(z)
+
+    def set_node_range(self, first, count):
+        self._chk(self.lib.feasthip_set_node_range(self.h, int(first), int(count)))
+
+    def set_solver(self, solver="direct", rtol=1e-12, atol=0.0, maxit=500, restart=30,
+                   factor_precision=64, cache_factors=True):
+        if solver not in _SOLVER_CODES:
+            raise ValueError(f"Unsupported solver option '{solver}'. Use :direct, :bicgstab, :gmres, or :iterative.")
+        self._chk(self.lib.feasthip_set_solver(self.h, _SOLVER_CODES[solver], float(rtol), float(atol), int(maxit),
+                                               int(restart), int(factor_precision), int(bool(cache_factors))))
+
+    # -- device arrays (plumbing) -----------------------------------------------------
+    def empty(self, m):
+        return self.torch.empty((m, self.N), dtype=self.torch.complex128, device=self.device)
+
+    def upload(self, Q):
+        """numpy N x m (any layout) -> device column-major block."""
+        Qc = np.ascontiguousarray(np.asarray(Q, dtype=np.complex128).T)
+        return self.torch.from_numpy(Qc).to(self.device)
+
+    def download(self, dQ, m=None):
+        a = dQ.cpu().numpy()
+        if m is not None:
+            a = a[:m]
+        return np.asfortranarray(a.T)
+
+    def allreduce_sum(self, dX, group=None):
+        """RCCL all-reduce over xGMI of a complex block (as 2*count f64), the image of
+        MPI.Allreduce in src/parallel/feast_mpi.jl:117-119, 856-858."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.torch.view_as_real(dX), op=dist.ReduceOp.SUM, group=group)
+        return dX
+
+    def _sync_stream(self):
+        self._chk(self.lib.feasthip_set_stream(
+            self.h, C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
+
+    # -- hot path -------------------------------------------------------------------
+    def contour_apply(self, dQ, m, ritz_lambda=None, want_moments=False):
+        """Q_proj (this rank's partial sum), per-node status, stats  [+ zAq, zSq]."""
+        self._sync_stream()
+        dP = self.empty(dQ.shape[0])
+        status = np.zeros(max(1, self.ne), dtype=np.int32)
+        stats = FeastHipStats()
+        lam = None if ritz_lambda is None else np.ascontiguousarray(ritz_lambda, dtype=np.float64)
+        dA = dS = None
+        if want_moments:
+            dA = self.torch.zeros((m, m), dtype=self.torch.complex128, device=self.device)
+            dS = self.torch.zeros((m, m), dtype=self.torch.complex128, device=self.device)
+        rc = self.lib.feasthip_contour_apply_dev(
+            self.h, m, C.c_void_p(dQ.data_ptr()), _np_ptr(lam), C.c_void_p(dP.data_ptr()),
+            C.c_void_p(dA.data_ptr()) if dA is not None else None,
+            C.c_void_p(dS.data_ptr()) if dS is not None else None,
+            _np_ptr(status), C.byref(stats))
+        self._chk(rc)
+        self.last_stats = stats.asdict()
+        if want_moments:
+            return dP, status, self.last_stats, dA.cpu().numpy().T.copy(), dS.cpu().numpy().T.copy()
+        return dP, status, self.last_stats
+
+    def orthonormalize(self, dQ, m, rank_tol):
+        self._sync_stream()
+        rank = C.c_int(0)
+        self._chk(self.lib.feasthip_orthonormalize_dev(self.h, m, C.c_void_p(dQ.data_ptr()), float(rank_tol), C.byref(rank)))
+        return rank.value
+
+    def project(self, dQ, r, bilinear=False, hermitize=True):
+        self._sync_stream()
+        Aq = np.zeros((r, r), dtype=np.complex128, order="F")
+        Bq = np.zeros((r, r), dtype=np.complex128, order="F")
+        self._chk(self.lib.feasthip_project_dev(self.h, r, C.c_void_p(dQ.data_ptr()), int(bilinear), int(hermitize),
+                                                _np_ptr(Aq), _np_ptr(Bq)))
+        return Aq, Bq
+
+    def ritz_residual(self, dQ, r, V, lam, M, normalize=True, use_B=True):
+        self._sync_stream()
+        Vf = np.asfortranarray(V, dtype=np.complex128)
+        lamc = np.ascontiguousarray(lam, dtype=np.complex128)
+        dX = self.empty(dQ.shape[0])
+        res = np.zeros(max(1, r), dtype=np.float64)
+        self._chk(self.lib.feasthip_ritz_residual_dev(self.h, r, C.c_void_p(dQ.data_ptr()), _np_ptr(Vf), _np_ptr(lamc),
+                                                      int(M), int(normalize), int(use_B), C.c_void_p(dX.data_ptr()),
+                                                      _np_ptr(res)))
+        return dX, res[:M].copy()
+
+    def matmul(self, which, dX, m):
+        self._sync_stream()
+        dY = self.empty(dX.shape[0])
+        self._chk(self.lib.feasthip_matmul_dev(self.h, int(which), m, C.c_void_p(dX.data_ptr()), C.c_void_p(dY.data_ptr())))
+        return dY
+
+    def shifted_solve(self, z, dX, m):
+        self._sync_stream()
+        dY = self.empty(dX.shape[0])
+        stats = FeastHipStats()
+        rc = self.lib.feasthip_shifted_solve_dev(self.h, float(np.real(z)), float(np.imag(z)), m,
+                                                 C.c_void_p(dX.data_ptr()), C.c_void_p(dY.data_ptr()), C.byref(stats))
+        self._chk(rc, ok=(0, 5, 8))
+        self.last_stats = stats.asdict()
+        return dY, rc
+
+    # -- measurement ----------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.feasthip_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.feasthip_profile_reset(self.h))
+
+    def profile_get(self, cls):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._chk(self.lib.feasthip_profile_get(self.h, cls.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        self._chk(self.lib.feasthip_synchronize(self.h))

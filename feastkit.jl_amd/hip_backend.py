@@ -1,0 +1,267 @@
+"""The ``:hip`` backend: host-side FEAST refinement loops that keep the reference's state
+machine and call the MI355X kernels through an *engine* (``engine.HipEngine``) for every
+per-quadrature-node operation.
+
+  feast_hip_hermitian  -- variant A ("QR + Rayleigh-Ritz"), mirrors
+        _feast_dense_complex_hermitian  src/dense/feast_dense.jl:78-351
+        _feast_sparse_hermitian         src/sparse/feast_sparse.jl:246-499
+  feast_hip_general    -- variant C maths of feast_grci!/feast_gegv!
+        src/kernel/feast_kernel.jl:646-962, src/dense/feast_dense.jl:402-593
+
+Quadrature nodes are block-partitioned over the ranks of a ``torch.distributed`` process
+group exactly like ``distribute_contour_points`` (src/parallel/feast_parallel.jl:433-447);
+each rank sweeps its nodes, Q_proj is summed with one all-reduce per refinement loop
+(RCCL over xGMI; the image of src/parallel/feast_mpi.jl:117-119) and every rank then runs
+the reduced eigenproblem redundantly, as the MPI path does (src/parallel/feast_mpi.jl:121-139).
+
+The reduced M0 x M0 eigenproblem stays on host LAPACK.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import scipy.linalg as sla
+
+from .contour import distribute_contour_points, feast_contour, feast_gcontour, feast_inside_gcontour
+from .parameters import check_feast_srci_input, feast_tolerance, feastdefault
+from .types import FeastError, FeastResult
+
+SQRT_EPS = math.sqrt(np.finfo(np.float64).eps)
+
+
+def seeded_subspace(N, M0, seed=20260515, complex_values=False):
+    """Initial subspace: real Gaussian columns of unit norm (src/core/feast_tools.jl:6-43).
+    The Julia MersenneTwister stream is not reproducible outside Julia; the structure is."""
+    rng = np.random.default_rng([seed, N, M0, int(complex_values)])
+    Q = rng.standard_normal((N, M0))
+    if complex_values:
+        Q = Q + 1j * rng.standard_normal((N, M0))
+    Q = Q.astype(np.complex128)
+    nrm = np.linalg.norm(Q, axis=0)
+    nrm[nrm == 0] = 1.0
+    return np.asfortranarray(Q / nrm)
+
+
+def _world(group):
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(group), dist.get_world_size(group)
+    except Exception:
+        pass
+    return 0, 1
+
+
+def _reorder_by_interval(lam, Emin, Emax, n):
+    """Stable inside-first permutation (src/core/feast_aux.jl:144-197) -> (perm, ninside)."""
+    inside = [i for i in range(n) if Emin <= lam[i] <= Emax]
+    outside = [i for i in range(n) if not (Emin <= lam[i] <= Emax)]
+    return np.array(inside + outside, dtype=np.int64), len(inside)
+
+
+def _reduced_hermitian_eig(Sq, Aq):
+    """eigen(Hermitian(Sq), Hermitian(Aq)) with the general fallback
+    (src/dense/feast_dense.jl:270-284)."""
+    try:
+        lam, V = sla.eigh(Sq, Aq)
+        return np.asarray(lam, dtype=np.float64), V
+    except Exception:
+        w, V = sla.eig(Sq, Aq)
+        return np.real(w).astype(np.float64), V
+
+
+def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0,
+                        solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
+                        group=None, Q0=None, seed=20260515, contour=None, trace=None):
+    """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
+    _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
+    does, src/dense/feast_dense.jl:372-387).
+
+    solver: "direct" (dense batched LU), "bicgstab"/"iterative" (batched BiCGStab), "gmres".
+    solver_tol: 0 -> 10^-fpm[3] like the reference.  Krylov stop test: ||r|| <= tol + tol*||r0||.
+    warm_start (iterative only, not in the reference): after the first loop the Ritz pairs
+      (lambda_j, q_j) seed the solves with Y0 = q_j/(z_e - lambda_j), whose residual is
+      r_j/(z_e - lambda_j) -- Galerkin-orthogonal to the current subspace.  ``inner_rtol``
+      then bounds the reduction relative to that initial residual (default solver_tol).
+    """
+    N = A.shape[0]
+    feastdefault(fpm)
+    info = check_feast_srci_input(N, M0, Emin, Emax)
+    if info:
+        return FeastResult(np.zeros(0), np.zeros((N, 0), dtype=np.complex128), 0, np.zeros(0), info, math.inf, 0)
+    if M0 > 64:
+        raise ValueError("the :hip backend currently takes M0 <= 64 per call (FH_MAX_LD)")
+    rank, world = _world(group)
+    iterative = solver not in ("direct", "lu")
+    tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
+
+    t_setup = time.perf_counter()
+    engine.set_problem(A, B)
+    if contour is None:
+        Zne, Wne = feast_contour(Emin, Emax, fpm)
+    else:
+        Zne, Wne = contour
+    engine.set_contour(Zne, Wne, 2.0)            # weight = 2*Wne[e]: src/dense/feast_dense.jl:174
+    first, count = distribute_contour_points(len(Zne), world)[rank]
+    engine.set_node_range(first, count)
+    engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
+                      restart=solver_restart, cache_factors=True)
+    if iterative and warm_start:
+        # inexact-solve mode: every loop reduces the (warm-started) residual by inner_rtol
+        rt = tol_value if inner_rtol is None else float(inner_rtol)
+        engine.set_solver(solver, rtol=rt, atol=0.0, maxit=solver_maxiter, restart=solver_restart)
+    t_setup = time.perf_counter() - t_setup
+
+    Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
+    dQ = engine.upload(Q_host)
+    maxloop = int(fpm[4])
+    eps_tol = feast_tolerance(fpm)
+    epsout, info, loop_count, M_found, active = math.inf, 0, 0, 0, M0
+    lam_vec = np.zeros(M0)
+    res_vec = np.zeros(M0)
+    ritz_lambda = None
+    dX = None
+    stats = {"setup_seconds": t_setup, "krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0,
+             "solve_seconds": 0.0, "loops": []}
+
+    for loop_idx in range(0, maxloop + 1):
+        loop_count = loop_idx
+        dP, status, st = engine.contour_apply(dQ, active, ritz_lambda if (iterative and warm_start) else None)
+        stats["krylov_iterations"] += st.get("krylov_iterations", 0)
+        stats["spmm_calls"] += st.get("spmm_calls", 0)
+        stats["factorizations"] += st.get("factorizations", 0)
+        stats["solve_seconds"] += st.get("seconds_solve", 0.0)
+        local_fail = int(np.max(status[:max(count, 1)])) if count > 0 else 0
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([float(local_fail)], dtype=torch.float64, device=dP.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            local_fail = int(flag.item())
+            engine.allreduce_sum(dP, group)
+        if local_fail == 8 or (local_fail == 5 and not warm_start):
+            # direct: singular shift -> info 8 (src/dense/feast_dense.jl:199-203);
+            # reference GMRES failure -> info 5 (src/dense/feast_dense.jl:221-225)
+            info = int(FeastError.Feast_ERROR_LAPACK if local_fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+
+        rank_q = engine.orthonormalize(dP, active, SQRT_EPS)       # _feast_qr_compress!
+        if rank_q == 0:
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
+        try:
+            lam_red, v_red = _reduced_hermitian_eig(Sq, Aq)
+        except Exception:
+            info = int(FeastError.Feast_ERROR_LAPACK)
+            break
+        perm, M = _reorder_by_interval(lam_red, Emin, Emax, rank_q)
+        lam_sorted = lam_red[perm]
+        V_sorted = np.asfortranarray(v_red[:, perm])
+        if trace is not None:
+            trace.append({"loop": loop_idx, "rank": rank_q, "M": M, "lambda": lam_sorted.copy(), "status": status.copy(),
+                          "stats": dict(st)})
+        if M == 0 and not (iterative and warm_start):
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+        lam_vec[:rank_q] = lam_sorted
+        if M > 0:
+            res_vec[:M] = res
+            epsout = float(res.max())
+        else:
+            epsout = math.inf
+        M_found = M
+        stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout,
+                               "krylov_iterations": st.get("krylov_iterations", 0)})
+        if M > 0 and epsout <= eps_tol:
+            break
+        if loop_idx == maxloop:
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        active = rank_q
+        dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
+        ritz_lambda = lam_sorted.copy()
+
+    if M_found == 0 and info == 0:
+        info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+    q = engine.download(dX, M_found) if (dX is not None and M_found > 0) else np.zeros((N, 0), dtype=np.complex128)
+    return FeastResult(lam_vec[:M_found].copy(), q, M_found, res_vec[:M_found].copy(), info, epsout, loop_count, stats)
+
+
+def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
+                      solver_restart=30, group=None, Q0=None, seed=20260515):
+    """Variant C (general, full contour, no factor 2, no orthonormalisation, residual
+    without B): src/kernel/feast_kernel.jl:752-950 driven as in src/dense/feast_dense.jl:468-584."""
+    N = A.shape[0]
+    feastdefault(fpm)
+    if N <= 0:
+        return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 1, math.inf, 0)
+    if M0 <= 0 or M0 > N:
+        return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 2, math.inf, 0)
+    if not r > 0:
+        return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 4, math.inf, 0)
+    if M0 > 64:
+        raise ValueError("the :hip backend currently takes M0 <= 64 per call (FH_MAX_LD)")
+    rank, world = _world(group)
+    iterative = solver not in ("direct", "lu")
+    tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
+    Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
+    Bc = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B) else B)
+    engine.set_problem(Ac, Bc)
+    Zne, Wne = feast_gcontour(Emid, r, fpm)
+    engine.set_contour(Zne, Wne, 1.0)
+    first, count = distribute_contour_points(len(Zne), world)[rank]
+    engine.set_node_range(first, count)
+    engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
+                      restart=solver_restart, cache_factors=True)
+    Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
+    dQ = engine.upload(Q_host)
+    eps_tol = feast_tolerance(fpm)
+    maxloop = int(fpm[4])
+    loop = 0
+    stats = {"krylov_iterations": 0, "factorizations": 0, "solve_seconds": 0.0}
+    while True:
+        dq, status, st = engine.contour_apply(dQ, M0, None)
+        stats["krylov_iterations"] += st.get("krylov_iterations", 0)
+        stats["factorizations"] += st.get("factorizations", 0)
+        stats["solve_seconds"] += st.get("seconds_solve", 0.0)
+        fail = int(np.max(status[:max(count, 1)])) if count > 0 else 0
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([float(fail)], dtype=torch.float64, device=dq.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            fail = int(flag.item())
+            engine.allreduce_sum(dq, group)
+        if fail:
+            return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0),
+                               int(FeastError.Feast_ERROR_LAPACK if fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE),
+                               math.inf, loop, stats)
+        Aq, Sq = engine.project(dq, M0, bilinear=False, hermitize=False)   # Aq = q^H A q, Sq = q^H B q
+        try:
+            lam_red, v_red = sla.eig(Aq, Sq)                                # feast_kernel.jl:812
+        except Exception:
+            return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0),
+                               int(FeastError.Feast_ERROR_LAPACK), math.inf, loop, stats)
+        ins = [i for i in range(M0) if feast_inside_gcontour(lam_red[i], Emid, r, fpm)]
+        M = len(ins)
+        if M == 0:
+            return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0),
+                               int(FeastError.Feast_ERROR_NO_CONVERGENCE), math.inf, loop, stats)
+        inset = set(ins)
+        perm = np.array(ins + [i for i in range(M0) if i not in inset], dtype=np.int64)
+        lam = lam_red[perm]
+        V = np.asfortranarray(v_red[:, perm])
+        # normalise ALL M0 columns (feast_kernel.jl:864-876); residual WITHOUT B (:899-906)
+        dX, res = engine.ritz_residual(dq, M0, V, lam, M0, normalize=True, use_B=False)
+        res = res[:M]
+        epsout = float(res.max())
+        if epsout <= eps_tol or loop >= maxloop:
+            order = sorted(range(M), key=lambda i: abs(lam[i]) ** 2)         # feast_sort_general!
+            X = engine.download(dX, M0)
+            return FeastResult(lam[:M][order].copy(), X[:, :M][:, order].copy(), M, res[order].copy(), 0, epsout, loop, stats)
+        loop += 1
+        dQ = dX

@@ -1,0 +1,201 @@
+/*
+ * feasthip.h -- C ABI of libfeasthip.so: the MI355X (gfx950) FEAST contour-integration
+ * inner loop that drops in behind FeastKit.jl's feast()/feast_general()/pfeast_* and RCI
+ * surfaces as a new `:hip` backend.
+ *
+ * The reference (subhk/FeastKit.jl v1.0.11) is pure Julia with no FFI of its own; the
+ * boundary below is derived from the seams an accelerator can sit behind without
+ * touching src/core or src/interfaces.  Each entry point cites
+ * the reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - POD arguments only.  No callbacks, no ownership transfer, no exceptions.
+ *   - Host matrices are COLUMN-MAJOR (Julia/Fortran); complex data is interleaved
+ *     (re,im) double pairs (Julia ComplexF64 / C99 double _Complex layout).
+ *   - "_dev" variants take DEVICE pointers in the same column-major layout and run
+ *     asynchronously on the handle's stream; the plain variants take host pointers,
+ *     copy in/out synchronously and never retain the pointer after return.
+ *   - Return value: 0 on success, else the reference's FeastError codes
+ *     (src/core/feast_types.jl:257-268): 1 N, 2 M0, 3 Emin/Emax, 4 Emid/r,
+ *     5 no convergence, 6 memory, 7 internal (HIP runtime), 8 LAPACK/singular, 9 fpm.
+ *     feasthip_last_error() returns a human-readable string for the last failure.
+ *   - One handle = one GPU = one host thread at a time (the reference's :threads
+ *     backend must not share a handle across Julia threads).
+ */
+#ifndef FEASTHIP_H
+#define FEASTHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FEASTHIP_VERSION_MAJOR 0
+#define FEASTHIP_VERSION_MINOR 1
+
+/* FeastError, src/core/feast_types.jl:257-268 */
+enum {
+    FEASTHIP_SUCCESS = 0,
+    FEASTHIP_ERROR_N = 1,
+    FEASTHIP_ERROR_M0 = 2,
+    FEASTHIP_ERROR_EMIN_EMAX = 3,
+    FEASTHIP_ERROR_EMID_R = 4,
+    FEASTHIP_ERROR_NO_CONVERGENCE = 5,
+    FEASTHIP_ERROR_MEMORY = 6,
+    FEASTHIP_ERROR_INTERNAL = 7,
+    FEASTHIP_ERROR_LAPACK = 8,
+    FEASTHIP_ERROR_FPM = 9
+};
+
+/* shifted-system solver kinds: keyword `solver` of feast_sygv!/feast_scsrgv!
+ * (src/dense/feast_dense.jl:81-84, src/sparse/feast_sparse.jl:249-252).          */
+enum {
+    FEASTHIP_SOLVER_LU = 0,        /* :direct  -- dense only (batched complex LU)          */
+    FEASTHIP_SOLVER_BICGSTAB = 1,  /* :iterative -- batched BiCGStab (Krylov.bicgstab,
+                                      src/interfaces/feast_matfree.jl:716)                 */
+    FEASTHIP_SOLVER_GMRES = 2      /* :gmres   -- batched restarted GMRES(m)
+                                      (src/sparse/feast_sparse.jl:183-188)                 */
+};
+
+enum { FEASTHIP_STORAGE_CSR = 0, FEASTHIP_STORAGE_CSC = 1 };
+
+typedef struct feasthip_ctx* feasthip_handle;
+
+/* Per-call statistics of feasthip_contour_apply (no reference counterpart; replaces the
+ * @warn/@debug diagnostics of src/parallel/feast_parallel.jl:266-273).                  */
+typedef struct feasthip_stats {
+    double  seconds_total;       /* wall time of the call (host clock)                       */
+    double  seconds_solve;       /* device time inside shifted solves (HIP events)            */
+    int64_t krylov_iterations;   /* sum over local nodes of max-over-columns iterations       */
+    int64_t spmm_calls;          /* operator applications (block of m columns each)           */
+    int64_t factorizations;      /* dense LU factorizations performed in this call            */
+    double  max_rel_residual;    /* max over nodes/columns of ||b - S y|| / ||b|| (iterative) */
+} feasthip_stats;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+int  feasthip_version(int* major, int* minor);
+/* device_id: HIP ordinal (one process per GPU: LOCAL_RANK). */
+int  feasthip_create(feasthip_handle* out, int device_id);
+int  feasthip_destroy(feasthip_handle h);
+const char* feasthip_last_error(feasthip_handle h);
+/* Run all work on an externally owned hipStream_t (e.g. torch's current stream). NULL
+ * restores the handle's own stream. */
+int  feasthip_set_stream(feasthip_handle h, void* hip_stream);
+int  feasthip_synchronize(feasthip_handle h);
+
+/* ---- problem definition ---------------------------------------------------------- */
+/* Dense A (and B, NULL => identity), column-major, lda/ldb >= N.
+ * Replaces the Matrix arguments of feast_sygv!/feast_hegv!/feast_gegv!
+ * (src/dense/feast_dense.jl:356, 402).  is_complex: 0 => double, 1 => interleaved c128. */
+int  feasthip_set_dense(feasthip_handle h, int64_t N, int is_complex,
+                        const void* A, int64_t lda, const void* B, int64_t ldb);
+
+/* Sparse A (and B, ptrB==NULL => identity).  Julia passes SparseMatrixCSC{T,Int64}
+ * (index_base 1, storage CSC); scipy passes CSR base 0.  For CSC input the library
+ * transposes on ingest, so results are for the matrix as the CALLER defines it
+ * (no silent conj/transpose).
+ * Replaces the SparseMatrixCSC arguments of feast_scsrgv!/feast_hcsrgv!/feast_gcsrgv!
+ * (src/sparse/feast_sparse.jl:713, 873) and pfeast_scsrgv! (src/parallel/feast_parallel.jl:450). */
+int  feasthip_set_csr(feasthip_handle h, int64_t N, int is_complex, int index_base, int storage,
+                      int64_t nnzA, const int64_t* ptrA, const int64_t* idxA, const void* valA,
+                      int64_t nnzB, const int64_t* ptrB, const int64_t* idxB, const void* valB);
+
+/* Contour nodes/weights as produced by feast_contour / feast_gcontour
+ * (src/core/feast_tools.jl:212-371): zne/wne are 2*ne doubles (re,im interleaved).
+ * weight_scale = 2.0 for the Hermitian half contour (src/dense/feast_dense.jl:174),
+ * 1.0 for the general full contour (src/kernel/feast_kernel.jl:762-766).              */
+int  feasthip_set_contour(feasthip_handle h, int ne, const double* zne, const double* wne,
+                          double weight_scale);
+
+/* Restrict this handle to nodes [first, first+count) -- the block partition of
+ * distribute_contour_points (src/parallel/feast_parallel.jl:433-447) /
+ * MPIFeastState (src/parallel/feast_mpi.jl:36-43).  Default: all nodes.              */
+int  feasthip_set_node_range(feasthip_handle h, int first, int count);
+
+/* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
+ * (src/dense/feast_dense.jl:81-84).  Iterative stop test is Krylov.jl's
+ * ||r_k|| <= atol + rtol*||r_0|| per column.  factor_precision 64|32 (dense LU only;
+ * 32 = c64 factors + fp64 iterative refinement).  cache_factors: keep LU factors per
+ * node across calls (src/dense/feast_dense.jl:147,188).                                 */
+int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit,
+                         int restart, int factor_precision, int cache_factors);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* One contour sweep over this handle's node range:
+ *     for e in local nodes:  Y_e = (z_e B - A)^{-1} (B Q);   Qproj += weight_scale*w_e*Y_e
+ *     optionally  zAq += weight_scale*w_e * Q^H Y_e,  zSq += weight_scale*w_e*z_e * Q^H Y_e
+ * Q, Qproj: N x m c128 column-major (ldq = N).  Qproj is OVERWRITTEN with this handle's
+ * partial sum (callers reduce across handles/ranks: src/parallel/feast_parallel.jl:497-503,
+ * src/parallel/feast_mpi.jl:117-119).  zAq/zSq: m x m c128 or NULL.
+ * ritz_lambda: NULL => zero initial guess (reference behaviour, Krylov.jl gmres);
+ *   else m doubles (real Ritz values paired with the columns of Q, as in
+ *   Q_basis <- solutions of src/dense/feast_dense.jl:336-337): iterative solvers start
+ *   from Y0[:,j] = Q[:,j]/(z_e - lambda_j).  Ignored by the LU solver.
+ * node_status[e_local]: 0 ok, 5 not converged, 8 singular.
+ * Replaces: loop bodies src/dense/feast_dense.jl:171-232, src/sparse/feast_sparse.jl:318-370,
+ * workers pfeast_solve_sparse_single_point (src/parallel/feast_parallel.jl:717-751) and
+ * mpi_compute_local_moments (src/parallel/feast_mpi.jl:206-253).                          */
+int  feasthip_contour_apply(feasthip_handle h, int64_t m, const void* Q, const double* ritz_lambda,
+                            void* Qproj, void* zAq, void* zSq, int* node_status,
+                            feasthip_stats* stats);
+int  feasthip_contour_apply_dev(feasthip_handle h, int64_t m, const void* dQ,
+                                const double* ritz_lambda_host, void* dQproj,
+                                void* dzAq, void* dzSq, int* node_status, feasthip_stats* stats);
+
+/* Rank-revealing orthonormalisation of Q[:, 0:m] in place.  Column-pivoted
+ * Gram-Schmidt with re-orthogonalisation; rank = #{ |R_ii| > max(rank_tol, eps*max(N,m))*|R_11| },
+ * the rule of _feast_qr_compress! (src/core/feast_aux.jl:101-131).  On return the first
+ * `rank` columns of Q hold the orthonormal basis.                                         */
+int  feasthip_orthonormalize(feasthip_handle h, int64_t m, void* Q, double rank_tol, int* rank);
+int  feasthip_orthonormalize_dev(feasthip_handle h, int64_t m, void* dQ, double rank_tol, int* rank);
+
+/* Rayleigh-Ritz projection: Aq = herm(Q^H A Q), Bq = herm(Q^H B Q) (Bq = I when
+ * B is the identity).  bilinear=1 uses Q^T (complex-symmetric siblings) and skips the
+ * Hermitian symmetrisation.  hermitize=0 returns the raw products (variant C,
+ * src/kernel/feast_kernel.jl:790,805).  Replaces src/dense/feast_dense.jl:252-265,
+ * src/sparse/feast_sparse.jl:392-405.  Aq, Bq: r x r c128 column-major HOST buffers.       */
+int  feasthip_project(feasthip_handle h, int64_t r, const void* Q, int bilinear, int hermitize,
+                      void* Aq, void* Bq);
+int  feasthip_project_dev(feasthip_handle h, int64_t r, const void* dQ, int bilinear, int hermitize,
+                          void* Aq_host, void* Bq_host);
+
+/* Ritz back-transform + residuals (SURVEY a12,a13):  X = Q*V (N x r), optional column
+ * normalisation of the first M columns, then res_j = ||A x_j - lambda_j B x_j||_2 / max(|lambda_j|,1)
+ * for j < M (use_B=0 drops B as the RCI kernels do, src/kernel/feast_kernel.jl:899-906).
+ * V: r x r c128 column-major host; lambda: r c128 host (re,im).
+ * Replaces src/dense/feast_dense.jl:287-322, src/core/feast_tools.jl:726-755.              */
+int  feasthip_ritz_residual(feasthip_handle h, int64_t r, const void* Q, const void* V,
+                            const double* lambda, int64_t M, int normalize, int use_B,
+                            void* X, double* res);
+int  feasthip_ritz_residual_dev(feasthip_handle h, int64_t r, const void* dQ, const void* V_host,
+                                const double* lambda_host, int64_t M, int normalize, int use_B,
+                                void* dX, double* res_host);
+
+/* ---- RCI / matrix-free seams -------------------------------------- */
+/* Y = op * X for op = A (which=0) or B (which=1): RCI jobs 30 / 40
+ * (src/core/feast_types.jl:227-249; callers src/dense/feast_dense.jl:561-573).          */
+int  feasthip_matmul(feasthip_handle h, int which, int64_t m, const void* X, void* Y);
+int  feasthip_matmul_dev(feasthip_handle h, int which, int64_t m, const void* dX, void* dY);
+
+/* Y = (z B - A)^{-1} X, all m columns: RCI jobs 10+11 and the matrix-free
+ * linear_solver(Y, z, X) callback contract (src/interfaces/feast_matfree.jl:149, 697).
+ * Unlike contour_apply the right-hand side is X itself (the caller applies B).          */
+int  feasthip_shifted_solve(feasthip_handle h, double z_re, double z_im, int64_t m,
+                            const void* X, void* Y, feasthip_stats* stats);
+int  feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double z_im, int64_t m,
+                                const void* dX, void* dY, feasthip_stats* stats);
+
+/* ---- measurement support ---------------------------------------------------------- */
+/* Average device time (ms, HIP events on the handle's stream) and launch count of the
+ * named kernel class since the last reset; classes: "spmm", "bicg_update", "dot_finalize",
+ * "lu_panel", "lu_gemm", "trsm", "gram", "ortho".  Used by bench.py's roofline object.     */
+int  feasthip_profile_enable(feasthip_handle h, int enable);
+int  feasthip_profile_reset(feasthip_handle h);
+int  feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms,
+                          int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEASTHIP_H */

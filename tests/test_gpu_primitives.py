@@ -1,0 +1,206 @@
+"""GPU parity of every C-ABI primitive against numpy/scipy (the oracle's arithmetic),
+through the ctypes binding.  Tolerances are fp64 round-off scaled by problem size."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+import feast_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_block(N, m, seed, cplx=True):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, m))
+    if cplx:
+        X = X + 1j * rng.standard_normal((N, m))
+    return np.asfortranarray(X.astype(np.complex128))
+
+
+def sparse_pair(N, seed, cplx=False, b_identity=False):
+    rng = np.random.default_rng(seed)
+    A = sp.random(N, N, density=min(1.0, 6.0 / N), random_state=seed, format="csr")
+    A = A + A.T + sp.diags(np.arange(1, N + 1, dtype=float))
+    if cplx:
+        S = sp.random(N, N, density=min(1.0, 3.0 / N), random_state=seed + 1, format="csr")
+        A = A + 1j * (S - S.T)
+    A = sp.csr_matrix(A)
+    if b_identity:
+        return A, None
+    B = sp.random(N, N, density=min(1.0, 3.0 / N), random_state=seed + 2, format="csr")
+    B = B + B.T + sp.diags(4.0 + rng.random(N))
+    return A, sp.csr_matrix(B)
+
+
+@pytest.mark.parametrize("N,m", [(50, 3), (257, 16), (1000, 17), (777, 32), (513, 48), (2049, 64)])
+@pytest.mark.parametrize("cplx,bid", [(False, False), (True, False), (False, True)])
+def test_spmm_matches_scipy(engine, N, m, cplx, bid):
+    A, B = sparse_pair(N, 11 + N + m, cplx, bid)
+    engine.set_problem(A, B)
+    X = rand_block(N, m, 5)
+    dX = engine.upload(X)
+    YA = engine.download(engine.matmul(0, dX, m))
+    YB = engine.download(engine.matmul(1, dX, m))
+    refA = A @ X
+    refB = X if B is None else B @ X
+    assert np.abs(YA - refA).max() <= 1e-12 * max(1.0, np.abs(refA).max())
+    assert np.abs(YB - refB).max() <= 1e-12 * max(1.0, np.abs(refB).max())
+
+
+@pytest.mark.parametrize("N,m", [(64, 4), (300, 16), (1000, 33), (515, 64)])
+@pytest.mark.parametrize("cplx,bid", [(False, False), (True, False), (False, True)])
+def test_dense_matmul(engine, N, m, cplx, bid):
+    rng = np.random.default_rng(N + m)
+    A = rng.standard_normal((N, N)); A = A + A.T
+    B = None
+    if cplx:
+        S = rng.standard_normal((N, N)); A = A + 1j * (S - S.T)
+    if not bid:
+        B = rng.standard_normal((N, N)); B = B @ B.T / N + np.eye(N)
+    engine.set_problem(A, B)
+    X = rand_block(N, m, 6)
+    dX = engine.upload(X)
+    YA = engine.download(engine.matmul(0, dX, m))
+    YB = engine.download(engine.matmul(1, dX, m))
+    refA, refB = A @ X, (X if B is None else B @ X)
+    assert np.abs(YA - refA).max() <= 1e-11 * np.abs(refA).max()
+    assert np.abs(YB - refB).max() <= 1e-11 * np.abs(refB).max()
+
+
+@pytest.mark.parametrize("N,m", [(40, 5), (300, 16), (1000, 32), (2000, 64)])
+def test_project_matches_numpy(engine, N, m):
+    A, B = sparse_pair(N, 3, cplx=True)
+    engine.set_problem(A, B)
+    Q = rand_block(N, m, 9)
+    dQ = engine.upload(Q)
+    Aq, Bq = engine.project(dQ, m, bilinear=False, hermitize=True)
+    refA = fo.hermitian_part(Q.conj().T @ (A @ Q))
+    refB = fo.hermitian_part(Q.conj().T @ (B @ Q))
+    assert np.abs(Aq - refA).max() <= 1e-11 * np.abs(refA).max()
+    assert np.abs(Bq - refB).max() <= 1e-11 * np.abs(refB).max()
+    Ar, Br = engine.project(dQ, m, bilinear=False, hermitize=False)
+    assert np.abs(Ar - Q.conj().T @ (A @ Q)).max() <= 1e-11 * np.abs(refA).max()
+    At, _ = engine.project(dQ, m, bilinear=True, hermitize=False)
+    assert np.abs(At - Q.T @ (A @ Q)).max() <= 1e-11 * np.abs(refA).max()
+
+
+@pytest.mark.parametrize("N,m,true_rank", [(30, 4, 4), (200, 16, 9), (1000, 32, 32), (3000, 64, 40), (500, 10, 3)])
+def test_orthonormalize_rank_and_span(engine, N, m, true_rank):
+    A, B = sparse_pair(N, 3)
+    engine.set_problem(A, B)
+    rng = np.random.default_rng(N)
+    basis = rng.standard_normal((N, true_rank)) + 1j * rng.standard_normal((N, true_rank))
+    mix = rng.standard_normal((true_rank, m)) + 1j * rng.standard_normal((true_rank, m))
+    src = np.asfortranarray(basis @ mix)
+    dQ = engine.upload(src)
+    rank = engine.orthonormalize(dQ, m, np.sqrt(np.finfo(float).eps))
+    Qo, rank_ref = fo.qr_compress(src, m)
+    assert rank == rank_ref == true_rank
+    Q = engine.download(dQ)[:, :rank]
+    assert np.abs(Q.conj().T @ Q - np.eye(rank)).max() < 1e-12
+    # same span as the pivoted-QR basis of the oracle and reproduces the source
+    assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= 1e-11 * np.linalg.norm(src)
+    assert np.linalg.norm(Qo - Q @ (Q.conj().T @ Qo)) <= 1e-10
+
+
+def test_orthonormalize_reference_kat(engine):
+    # rank-compress KAT of the reference (test/test_allocation_helpers.jl:274-292): 4x4, rank 2
+    A, B = sparse_pair(4, 3)
+    engine.set_problem(A, B)
+    src = np.array([[1, 2, 3, 4], [0, 1, 1, 2], [2, 5, 7, 10], [1, 1, 2, 2]], dtype=np.complex128)
+    ref_rank = np.linalg.matrix_rank(src)
+    dQ = engine.upload(src)
+    rank = engine.orthonormalize(dQ, 4, np.sqrt(np.finfo(float).eps))
+    assert rank == ref_rank == fo.qr_compress(src, 4)[1]
+    Q = engine.download(dQ)[:, :rank]
+    assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= 1e-12 * np.linalg.norm(src)
+
+
+@pytest.mark.parametrize("N,r,M", [(60, 6, 3), (400, 16, 16), (1500, 30, 11), (2500, 64, 44)])
+@pytest.mark.parametrize("use_B", [True, False])
+def test_ritz_residual(engine, N, r, M, use_B):
+    A, B = sparse_pair(N, 21)
+    engine.set_problem(A, B)
+    Q = rand_block(N, r, 2)
+    V = rand_block(r, r, 3)
+    lam = np.linspace(0.5, 3.0, r) + 0j
+    dQ = engine.upload(Q)
+    dX, res = engine.ritz_residual(dQ, r, V, lam, M, normalize=True, use_B=use_B)
+    X = Q @ V
+    X[:, :M] /= np.linalg.norm(X[:, :M], axis=0)
+    Xg = engine.download(dX)
+    assert np.abs(Xg - X).max() <= 1e-11 * np.abs(X).max()
+    ref = fo.feast_residual(A, B if use_B else None, lam.real, X, M)
+    assert np.abs(res - ref).max() <= 1e-10 * ref.max()
+
+
+@pytest.mark.parametrize("N,m", [(200, 7), (1000, 32), (3000, 64)])
+def test_bicgstab_shifted_solve(engine, N, m):
+    # well-conditioned shifted system: z far from the (real) spectrum
+    A, B = sparse_pair(N, 5)
+    engine.set_problem(A, B)
+    engine.set_solver("bicgstab", rtol=1e-12, atol=0.0, maxit=4000)
+    z = -3.0 + 2.0j
+    X = rand_block(N, m, 8)
+    dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    assert rc == 0
+    Y = engine.download(dY)
+    S = (z * B - A).tocsc()
+    ref = sp.linalg.splu(S).solve(X)
+    rel = np.linalg.norm(S @ Y - X, axis=0) / np.linalg.norm(X, axis=0)
+    assert rel.max() < 1e-10
+    assert np.abs(Y - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("N,m", [(33, 5), (100, 10), (500, 32), (1111, 64)])
+@pytest.mark.parametrize("cplx,bid", [(False, True), (False, False), (True, False)])
+def test_dense_lu_shifted_solve(engine, N, m, cplx, bid):
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((N, N)); A = A + A.T
+    if cplx:
+        S = rng.standard_normal((N, N)); A = A + 1j * (S - S.T)
+    B = None
+    if not bid:
+        B = rng.standard_normal((N, N)); B = B @ B.T / N + np.eye(N)
+    engine.set_problem(A, B)
+    engine.set_solver("direct")
+    z = 0.3 + 0.7j
+    X = rand_block(N, m, 4)
+    dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    assert rc == 0
+    Y = engine.download(dY)
+    Sm = z * (np.eye(N) if B is None else B) - A
+    ref = sla.lu_solve(sla.lu_factor(Sm), X)
+    assert np.abs(Y - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert (np.linalg.norm(Sm @ Y - X, axis=0) / np.linalg.norm(X, axis=0)).max() < 1e-11
+
+
+def test_contour_apply_matches_oracle_sum(engine):
+    # Q_proj = sum_e 2 w_e (z_e B - A)^{-1} B Q and the variant-B moments, dense LU path
+    N, m = 120, 12
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((N, N)); A = A + A.T
+    B = rng.standard_normal((N, N)); B = B @ B.T / N + np.eye(N)
+    Zne, Wne = fo.feast_contour(-1.0, 1.0, 8)
+    engine.set_problem(A, B)
+    engine.set_contour(Zne, Wne, 2.0)
+    engine.set_solver("direct")
+    Q = rand_block(N, m, 1, cplx=False)
+    dP, status, stats, zAq, zSq = engine.contour_apply(engine.upload(Q), m, None, want_moments=True)
+    assert (status[:8] == 0).all() and stats["factorizations"] == 8
+    ref = np.zeros((N, m), complex); rA = np.zeros((m, m), complex); rS = np.zeros((m, m), complex)
+    for z, w in zip(Zne, Wne):
+        Y = np.linalg.solve(z * B - A, B @ Q)
+        ref += 2 * w * Y
+        rA += 2 * w * (Q.conj().T @ Y)
+        rS += 2 * w * z * (Q.conj().T @ Y)
+    assert np.abs(engine.download(dP) - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert np.abs(zAq - rA).max() <= 1e-10 * np.abs(rA).max()
+    assert np.abs(zSq - rS).max() <= 1e-10 * np.abs(rS).max()
+    # node range = block partition: partial sums add up
+    engine.set_node_range(0, 3)
+    p0 = engine.download(engine.contour_apply(engine.upload(Q), m)[0])
+    engine.set_node_range(3, 5)
+    p1 = engine.download(engine.contour_apply(engine.upload(Q), m)[0])
+    assert np.abs(p0 + p1 - ref).max() <= 1e-10 * np.abs(ref).max()
