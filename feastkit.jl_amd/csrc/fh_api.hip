@@ -312,6 +312,12 @@ extern "C" int feasthip_set_contour(feasthip_handle h, int ne, const double* zne
     return 0;
 }
 
+extern "C" int feasthip_set_real_projection(feasthip_handle h, int real_part) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    h->real_projection = real_part ? 1 : 0;
+    return 0;
+}
+
 extern "C" int feasthip_set_node_range(feasthip_handle h, int first, int count) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     if (first < 0 || count < 0 || first + count > (int)h->zne.size()) {
@@ -340,9 +346,10 @@ extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, dou
 // ---------------------------------------------------------------------------------------
 // operator application on panels (sparse or dense):  Y = (cb*B + ca*A) X  per column
 // ---------------------------------------------------------------------------------------
-static int fh_spmm_nblk(int N) {
+static int fh_spmm_nblk(int N, int nodes) {
     int nb = (N + 15) / 16;
-    if (nb > 2048) nb = 2048;
+    int cap = 2048 / (nodes < 1 ? 1 : (nodes > 8 ? 8 : nodes));
+    if (nb > cap) nb = cap;
     if (nb < 8) nb = 8;
     return (nb + 7) / 8 * 8;
 }
@@ -368,7 +375,7 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = c.Bvec; a.b_node_stride = c.b_stride;
         a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
         a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
-        int nblk = fh_spmm_nblk(a.N);
+        int nblk = fh_spmm_nblk(a.N, c.nodes);
         fh_prof_begin(h, "spmm");
         fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, nblk, h->stream);
         fh_prof_end(h);
@@ -387,8 +394,8 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
     return nblk;
 }
 
-static int fh_op_nblk(feasthip_ctx* h) {
-    return h->kind == 2 ? fh_spmm_nblk((int)h->csr.N) : fh_dense_op_nblk((int)h->dense.N);
+static int fh_op_nblk(feasthip_ctx* h, int nodes = 1) {
+    return h->kind == 2 ? fh_spmm_nblk((int)h->csr.N, nodes) : fh_dense_op_nblk((int)h->dense.N);
 }
 static int64_t fh_N(feasthip_ctx* h) { return h->kind == 2 ? h->csr.N : h->dense.N; }
 static bool fh_b_identity(feasthip_ctx* h) { return h->kind == 2 ? h->csr.b_identity != 0 : h->dense.b_identity != 0; }
@@ -447,8 +454,8 @@ static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vec
     if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
     s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
     int* d_count = s.node_active + nodes;
-    const int nblk_op = fh_op_nblk(h);
-    const int nblk_vec = fh_vec_nblk(N, ld);
+    const int nblk_op = fh_op_nblk(h, nodes);
+    const int nblk_vec = fh_kry_nblk(N, ld, nodes);
     const int nblk_max = std::max(nblk_op, nblk_vec);
     if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
     cplx* part1 = (cplx*)p;
@@ -650,7 +657,7 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     cplx* dw;
     if ((rc = fh_upload_coefs(h, "ca_w", w, &dw))) return rc;
     fh_prof_begin(h, "accumulate");
-    fh_launch_accumulate(Y, panel, dw, nodes, N, ld, Outp, h->stream);
+    fh_launch_accumulate(Y, panel, dw, nodes, N, ld, Outp, h->real_projection, h->stream);
     fh_prof_end(h);
     fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream);
 
@@ -675,6 +682,7 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
                     cfma(sq[(size_t)c2 * m + c1], wz, g);
                 }
         }
+        if (h->real_projection) for (size_t i = 0; i < aq.size(); ++i) { aq[i].y = 0.0; sq[i].y = 0.0; }
         if (dzAq) FH_CHECK(hipMemcpyAsync(dzAq, aq.data(), aq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
         if (dzSq) FH_CHECK(hipMemcpyAsync(dzSq, sq.data(), sq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
     }
@@ -741,7 +749,7 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
     cplx* X = (cplx*)p;
     if ((rc = fh_get_buf(h, "or_out", panel * sizeof(cplx), &p))) return rc;
     cplx* Out = (cplx*)p;
-    if ((rc = fh_get_buf(h, "or_work", (size_t)1024 * ld * sizeof(cplx), &p))) return rc;
+    if ((rc = fh_get_buf(h, "or_work", (size_t)256 * ld * sizeof(cplx), &p))) return rc;
     cplx* work = (cplx*)p;
     if ((rc = fh_get_buf(h, "or_istate", (4 + FH_MAX_LD) * sizeof(int), &p))) return rc;
     int* istate = (int*)p;

@@ -66,18 +66,19 @@ void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int6
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FH_BLOCK) void k_accumulate(const cplx* __restrict__ X, size_t node_stride,
                                                           const cplx* __restrict__ w, int nodes, size_t total,
-                                                          cplx* __restrict__ dst) {
+                                                          cplx* __restrict__ dst, int real_part) {
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         cplx acc = cmake(0, 0);
         for (int n = 0; n < nodes; ++n) cfma(acc, w[n], X[(size_t)n * node_stride + e]);
+        if (real_part) acc.y = 0.0;
         dst[e] = acc;
     }
 }
 void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld,
-                          cplx* dst, hipStream_t st) {
+                          cplx* dst, int real_part, hipStream_t st) {
     size_t total = (size_t)N * ld;
     int nblk = (int)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048);
-    hipLaunchKernelGGL(k_accumulate, dim3(nblk), dim3(FH_BLOCK), 0, st, X, node_stride, w, nodes, total, dst);
+    hipLaunchKernelGGL(k_accumulate, dim3(nblk), dim3(FH_BLOCK), 0, st, X, node_stride, w, nodes, total, dst, real_part);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -86,7 +87,18 @@ void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int 
 int fh_vec_nblk(int N, int ld) {
     size_t total = (size_t)N * ld;
     size_t nb = (total + FH_BLOCK * 4 - 1) / (FH_BLOCK * 4);
-    if (nb > 1024) nb = 1024;
+    if (nb > 256) nb = 256;
+    if (nb < 8) nb = 8;
+    return (int)((nb + 7) / 8 * 8);
+}
+
+// blocks per node for the batched Krylov kernels: enough blocks to fill 256 CUs, few enough
+// partial sums that the per-node finalize kernels stay short (256 per node at >= 8 nodes).
+int fh_kry_nblk(int N, int ld, int nodes) {
+    size_t total = (size_t)N * ld;
+    size_t nb = (total + FH_BLOCK * 4 - 1) / (FH_BLOCK * 4);
+    size_t cap = 2048 / (size_t)(nodes < 1 ? 1 : (nodes > 8 ? 8 : nodes));
+    if (nb > cap) nb = cap;
     if (nb < 8) nb = 8;
     return (int)((nb + 7) / 8 * 8);
 }
@@ -468,7 +480,7 @@ __global__ void k_mgs_init(int* istate, int ld) {
 template <int LD>
 static void mgs_run_ld(const fh_mgs_args& a, hipStream_t st) {
     const int RPB = FH_BLOCK / LD;
-    int nblk = std::min((a.N + RPB * 4 - 1) / (RPB * 4), 1024);
+    int nblk = std::min((a.N + RPB * 4 - 1) / (RPB * 4), 256);
     if (nblk < 1) nblk = 1;
     int nblk_flat = fh_vec_nblk(a.N, LD);
     size_t total = (size_t)a.N * LD;

@@ -105,6 +105,7 @@ struct feasthip_ctx {
     // contour
     std::vector<cplx> zne, wne;
     double weight_scale = 2.0;
+    int real_projection = 0;
     int node_first = 0, node_count = 0;
 
     // solver options

@@ -53,7 +53,7 @@ void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int6
 void fh_launch_to_panel_real(const double* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
 // dst = sum_e w[e] * X[e]
 void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld,
-                          cplx* dst, hipStream_t st);
+                          cplx* dst, int real_part, hipStream_t st);
 // G (ld x ld, column-major, ldg = ld) = X^H Y (bilinear=0) or X^T Y (bilinear=1); f64 MFMA.
 // work: at least fh_gram_work_elems(ld) cplx.
 size_t fh_gram_work_elems(int ld);
@@ -61,6 +61,7 @@ void fh_launch_gram(const cplx* X, const cplx* Y, int N, int ld, int bilinear, c
                     hipStream_t st);
 // per-column dots: out[c] = <U[:,c], V[:,c]>; work: nblk*ld cplx
 int fh_vec_nblk(int N, int ld);
+int fh_kry_nblk(int N, int ld, int nodes);
 void fh_launch_dot_cols(const cplx* U, const cplx* V, int N, int ld, cplx* work, cplx* out, hipStream_t st);
 // X[:,c] *= s[c]
 void fh_launch_scale_cols(cplx* X, const cplx* s, int N, int ld, hipStream_t st);

@@ -235,11 +235,12 @@ __global__ __launch_bounds__(FH_BLOCK) void k_xr_update(fh_vec_args a) {
 }
 
 // ---- finalize kernels: one block per node, reduce the per-block partials ---------------
+#define FH_FIN_BLOCK 1024
 template <int LD>
 __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, int nblk, cplx* red) {
     const int t = threadIdx.x;
     const int c = t % LD, g = t / LD;
-    constexpr int G = FH_BLOCK / LD;
+    constexpr int G = FH_FIN_BLOCK / LD;
     cplx s = cmake(0, 0);
     const cplx* p = partial + (size_t)node * nblk * LD;
     for (int b = g; b < nblk; b += G) s = cadd(s, p[(size_t)b * LD + c]);
@@ -257,9 +258,9 @@ __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, i
 __device__ __forceinline__ bool fh_finite(cplx a) { return isfinite(a.x) && isfinite(a.y); }
 
 template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_fin_init(fh_fin_args a) {
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_init(fh_fin_args a) {
     // after R = b - S X0 with partial2 = <R,R>: set r0norm, target, rho = <rhat,r> = ||r||^2
-    __shared__ cplx red[FH_BLOCK];
+    __shared__ cplx red[FH_FIN_BLOCK];
     __shared__ int cnt;
     const int node = blockIdx.x, t = threadIdx.x;
     if (t == 0) cnt = 0;
@@ -286,9 +287,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_fin_init(fh_fin_args a) {
 }
 
 template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_fin_alpha(fh_fin_args a) {
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_alpha(fh_fin_args a) {
     // alpha = rho / <rhat, v>
-    __shared__ cplx red[FH_BLOCK];
+    __shared__ cplx red[FH_FIN_BLOCK];
     const int node = blockIdx.x, t = threadIdx.x;
     if (a.s.node_active[node] == 0) return;
     cplx sigma = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_fin_alpha(fh_fin_args a) {
 }
 
 template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_fin_omega(fh_fin_args a) {
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_omega(fh_fin_args a) {
     // omega = <t,s> / <t,t>
-    __shared__ cplx red[FH_BLOCK];
+    __shared__ cplx red[FH_FIN_BLOCK];
     const int node = blockIdx.x, t = threadIdx.x;
     if (a.s.node_active[node] == 0) return;
     cplx ts = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
@@ -325,9 +326,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_fin_omega(fh_fin_args a) {
 }
 
 template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_fin_rho(fh_fin_args a) {
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_rho(fh_fin_args a) {
     // rho_new = <rhat, r>, beta = (rho_new/rho)(alpha/omega); convergence bookkeeping
-    __shared__ cplx red[FH_BLOCK];
+    __shared__ cplx red[FH_FIN_BLOCK];
     __shared__ int cnt;
     const int node = blockIdx.x, t = threadIdx.x;
     if (a.s.node_active[node] == 0) return;
@@ -394,17 +395,23 @@ void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipSt
 void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
     FH_DISPATCH_LD(ld, k_xr_update, dim3(nblk, nodes), st, a);
 }
+#define FH_DISPATCH_FIN(ld, KERNEL, grid, st, args)                                           \
+    do {                                                                                        \
+        if ((ld) == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(FH_FIN_BLOCK), 0, st, args); \
+        else if ((ld) == 32) hipLaunchKernelGGL((KERNEL<32>), grid, dim3(FH_FIN_BLOCK), 0, st, args); \
+        else hipLaunchKernelGGL((KERNEL<64>), grid, dim3(FH_FIN_BLOCK), 0, st, args);           \
+    } while (0)
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_fin_init, dim3(nodes), st, a);
+    FH_DISPATCH_FIN(ld, k_fin_init, dim3(nodes), st, a);
 }
 void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_fin_alpha, dim3(nodes), st, a);
+    FH_DISPATCH_FIN(ld, k_fin_alpha, dim3(nodes), st, a);
 }
 void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_fin_omega, dim3(nodes), st, a);
+    FH_DISPATCH_FIN(ld, k_fin_omega, dim3(nodes), st, a);
 }
 void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_fin_rho, dim3(nodes), st, a);
+    FH_DISPATCH_FIN(ld, k_fin_rho, dim3(nodes), st, a);
 }
 void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st) {
     hipLaunchKernelGGL(k_count_active, dim3(1), dim3(64), 0, st, node_active, nodes, out);

@@ -115,6 +115,9 @@ class HipEngine:
         self._chk(self.lib.feasthip_set_contour(self.h, len(z), _np_ptr(z), _np_ptr(w), float(weight_scale)))
         self.ne = len(z)
 
+    def set_real_projection(self, on):
+        self._chk(self.lib.feasthip_set_real_projection(self.h, int(bool(on))))
+
     def set_node_range(self, first, count):
         self._chk(self.lib.feasthip_set_node_range(self.h, int(first), int(count)))
 

@@ -74,7 +74,7 @@ def _reduced_hermitian_eig(Sq, Aq):
 
 def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
-                        group=None, Q0=None, seed=20260515, contour=None, trace=None):
+                        real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -85,6 +85,11 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
       (lambda_j, q_j) seed the solves with Y0 = q_j/(z_e - lambda_j), whose residual is
       r_j/(z_e - lambda_j) -- Galerkin-orthogonal to the current subspace.  ``inner_rtol``
       then bounds the reduction relative to that initial residual (default solver_tol).
+    real_projection: None -> True for real-symmetric A, B.  Q_proj = Re(sum 2 w_e Y_e), the
+      full-contour FEAST filter (what the reference's real paths do, feast_parallel.jl:38-55,
+      feast_kernel.jl:183-186).  False keeps variant A's complex half-contour sum
+      (feast_dense.jl:231), whose filter only decays like 1/distance: same converged
+      eigenpairs, many more refinement loops.
     """
     N = A.shape[0]
     feastdefault(fpm)
@@ -104,6 +109,12 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
     else:
         Zne, Wne = contour
     engine.set_contour(Zne, Wne, 2.0)            # weight = 2*Wne[e]: src/dense/feast_dense.jl:174
+    if real_projection is None:
+        import scipy.sparse as _sp
+        _isc = lambda M_: M_ is not None and np.iscomplexobj(M_.data if _sp.issparse(M_) else M_)
+        real_projection = not (_isc(A) or _isc(B)) and (Q0 is None or not np.iscomplexobj(Q0) or
+                                                        not np.any(np.imag(Q0)))
+    engine.set_real_projection(bool(real_projection))
     first, count = distribute_contour_points(len(Zne), world)[rank]
     engine.set_node_range(first, count)
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
@@ -213,6 +224,7 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
     engine.set_problem(Ac, Bc)
     Zne, Wne = feast_gcontour(Emid, r, fpm)
     engine.set_contour(Zne, Wne, 1.0)
+    engine.set_real_projection(False)
     first, count = distribute_contour_points(len(Zne), world)[rank]
     engine.set_node_range(first, count)
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,

@@ -108,6 +108,15 @@ int  feasthip_set_csr(feasthip_handle h, int64_t N, int is_complex, int index_ba
 int  feasthip_set_contour(feasthip_handle h, int ne, const double* zne, const double* wne,
                           double weight_scale);
 
+/* real_part = 1: Qproj (and zAq/zSq) receive only the REAL part of the weighted sum,
+ * Qproj = Re( sum_e 2 w_e Y_e ).  For real-symmetric A, B and a real Q this equals the sum
+ * over the full contour (the conjugate half is the complex conjugate), i.e. the true FEAST
+ * rational filter -- what the reference's real paths do: _pfeast_store_real_moments!
+ * (src/parallel/feast_parallel.jl:38-55), feast_srci! (src/kernel/feast_kernel.jl:143,183-186).
+ * real_part = 0 (default) keeps the complex half-contour sum of the complexified variant A
+ * (src/dense/feast_dense.jl:231).                                                        */
+int  feasthip_set_real_projection(feasthip_handle h, int real_part);
+
 /* Restrict this handle to nodes [first, first+count) -- the block partition of
  * distribute_contour_points (src/parallel/feast_parallel.jl:433-447) /
  * MPIFeastState (src/parallel/feast_mpi.jl:36-43).  Default: all nodes.              */
