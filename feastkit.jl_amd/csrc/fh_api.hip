@@ -833,9 +833,11 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
         cplx* out_host = (cplx*)(which == 0 ? Aq_host : Bq_host);
         if (!out_host) continue;
         std::vector<cplx> res((size_t)r * r);
-        if (which == 1 && fh_b_identity(h)) {
+        if (which == 1 && fh_b_identity(h) && hermitize && !bilinear) {
+            // variant A: Q is orthonormal, Aq_rank = I exactly (src/dense/feast_dense.jl:255-259)
             for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) res[(size_t)j * r + i] = cmake(i == j ? 1.0 : 0.0, 0.0);
         } else {
+            // (B = I without orthonormal Q, variant C: the operator kernel yields W = Q, so G = Q^H Q)
             fh_op_call oc;
             oc.X = Qp; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
             oc.coefA = which == 0 ? d1 : d0; oc.coefB = which == 0 ? d0 : d1;

@@ -161,7 +161,7 @@ int  feasthip_orthonormalize_dev(feasthip_handle h, int64_t m, void* dQ, double 
 
 /* Rayleigh-Ritz projection: Aq = herm(Q^H A Q), Bq = herm(Q^H B Q) (Bq = I when
  * B is the identity).  bilinear=1 uses Q^T (complex-symmetric siblings) and skips the
- * Hermitian symmetrisation.  hermitize=0 returns the raw products (variant C,
+ * Hermitian symmetrisation.  hermitize=0 returns the raw products, Bq = Q^H Q for B = I (variant C,
  * src/kernel/feast_kernel.jl:790,805).  Replaces src/dense/feast_dense.jl:252-265,
  * src/sparse/feast_sparse.jl:392-405.  Aq, Bq: r x r c128 column-major HOST buffers.       */
 int  feasthip_project(feasthip_handle h, int64_t r, const void* Q, int bilinear, int hermitize,

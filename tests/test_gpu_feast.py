@@ -1,0 +1,237 @@
+"""End-to-end parity of the :hip backend (through the C ABI, on the GPU) against the CPU
+oracle and the reference's own known-answer fixtures.  Parity is asserted on converged
+quantities only (eigenvalues, residuals, M, info): the reference's initial subspace comes
+from Julia's MersenneTwister and is not reproducible."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import feast_oracle as fo
+import feastkit_jl_amd as fk
+from kat_util import cmat, cplx, load_kats, sparse_tridiag, tridiag
+
+pytestmark = pytest.mark.gpu
+K = load_kats()
+
+
+def fpm_with(**kw):
+    fpm = fk.feastinit()
+    for k, v in kw.items():
+        fpm[int(k[1:])] = v
+    return fpm
+
+
+def test_tridiag3_real_symmetric(engine):
+    k = K["tridiag3_real_sym"]
+    r = fk.feast(tridiag(3), np.eye(3), tuple(k["interval"]), M0=3, engine=engine)
+    assert r.info == 0 and r.M == 3 and not np.iscomplexobj(r.q)
+    assert np.allclose(np.sort(r.lambda_), sorted(k["expect_lambda"]), atol=k["atol"])
+
+
+@pytest.mark.parametrize("name", ["hermitian3_dense", "hermitian3_sparse"])
+def test_hermitian3(engine, name):
+    k = K[name]
+    A = cmat(k["A"])
+    if name.endswith("sparse"):
+        r = fk.feast(sp.csr_matrix(A), None, tuple(k["interval"]), M0=3, engine=engine, solver="bicgstab", solver_maxiter=200)
+    else:
+        r = fk.feast(A, None, tuple(k["interval"]), M0=3, engine=engine)
+    assert r.info == 0 and r.M == 3
+    assert np.allclose(np.sort(r.lambda_), k["expect_lambda"], atol=k["atol"])
+    # eigenvectors: residual against the full matrix on the host
+    for j in range(3):
+        x = r.q[:, j]
+        assert np.linalg.norm(A @ x - r.lambda_[j] * x) <= 1e-9 * np.linalg.norm(x)
+
+
+def test_general2_dense(engine):
+    k = K["general2"]
+    A, B = cmat(k["A"]), cmat(k["B"])
+    r = fk.feast_general(A, None, cplx(k["center"]), k["radius"], M0=2, engine=engine)
+    assert r.info == 0 and r.M == 2 and np.allclose(np.sort(r.lambda_.real), k["expect_standard"], atol=k["atol"])
+    r = fk.feast_general(A, B, cplx(k["center"]), k["radius"], M0=2, engine=engine)
+    assert r.info == 0 and r.M == 2 and np.allclose(np.sort(r.lambda_.real), k["expect_generalized"], atol=k["atol"])
+    r = fk.feast_general(np.array([[1.0, 2.0], [0.0, 3.0]]), None, 2.0, 2.5, M0=2, engine=engine)   # real promotion
+    assert r.info == 0 and r.M == 2 and np.allclose(np.sort(r.lambda_.real), [1.0, 3.0], atol=1e-9)
+
+
+def test_diag80_oversized_subspace_rank_compression(engine):
+    k = K["diag80_oversized"]
+    A = np.diag(np.arange(1.0, 81))
+    fpm = fpm_with(f2=k["fpm2"], f3=k["fpm3"], f4=k["fpm4"])
+    for real_projection in (False, True):
+        r = fk.feast(A, None, tuple(k["interval"]), M0=k["M0"], fpm=fpm.copy(), engine=engine, real_projection=real_projection)
+        assert r.info == 0 and r.M == 2
+        assert np.allclose(np.sort(r.lambda_), k["expect_lambda"], atol=k["atol"]) and r.res.max() < k["max_res"]
+    ref = fo.feast_hermitian(A, None, *k["interval"], k["M0"], ne=8, fpm3=7, fpm4=4)
+    assert ref.M == 2
+
+
+def test_tridiag10_all_partitions_agree(engine):
+    k = K["tridiag10_backends"]
+    A = sparse_tridiag(10)
+    fpm = fpm_with(f2=8, f4=20)
+    r = fk.feast(A.toarray(), None, tuple(k["interval"]), M0=10, fpm=fpm.copy(), engine=engine)
+    assert r.info == 0 and np.allclose(np.sort(r.lambda_), k["expect_lambda"], atol=k["atol"])
+    rs = fk.feast(A, None, tuple(k["interval"]), M0=10, fpm=fpm.copy(), engine=engine, solver="bicgstab", solver_maxiter=500)
+    assert rs.info == 0 and np.allclose(np.sort(rs.lambda_), k["expect_lambda"], atol=k["atol"])
+
+
+def test_hermitian_generalized_diag6(engine):
+    k = K["hermitian_generalized_diag6"]
+    A = sp.diags(np.array(k["A_diag"], dtype=complex)).tocsr()
+    B = sp.diags(np.array(k["B_diag"], dtype=complex)).tocsr()
+    r = fk.feast(A, B, tuple(k["interval"]), M0=6, engine=engine, solver="bicgstab")
+    assert r.info == 0 and r.M == len(k["expect_lambda"])
+    assert np.allclose(np.sort(r.lambda_), k["expect_lambda"], atol=k["atol"])
+    rd = fk.feast(A.toarray(), B.toarray(), tuple(k["interval"]), M0=6, engine=engine)
+    assert rd.info == 0 and np.allclose(np.sort(rd.lambda_), k["expect_lambda"], atol=k["atol"])
+
+
+def test_iterative_equals_direct_tridiag12(engine):
+    k = K["gmres_equiv_tridiag12"]
+    A = sparse_tridiag(12)
+    d = fk.feast(A.toarray(), None, tuple(k["interval"]), M0=12, engine=engine)
+    g = fk.feast(A, None, tuple(k["interval"]), M0=12, engine=engine, solver="bicgstab", solver_tol=k["solver_tol"],
+                 solver_maxiter=k["maxiter"])
+    assert d.info == 0 and g.info == 0 and d.M == g.M == len(k["expect_lambda"])
+    assert np.allclose(np.sort(g.lambda_), np.sort(d.lambda_), atol=k["atol"])
+
+
+def test_mpi_complex_fixtures(engine):
+    k = K["mpi_complex_hermitian_diag4"]
+    A = sp.diags(np.array(k["diag"], dtype=complex)).tocsr()
+    r = fk.feast(A, sp.identity(4, dtype=complex, format="csr"), tuple(k["interval"]), M0=4, fpm=fpm_with(f2=8, f4=12),
+                 engine=engine, solver="bicgstab")
+    assert r.info == 0 and np.allclose(np.sort(r.lambda_), k["expect_lambda"], atol=k["atol"])
+    g = K["mpi_complex_general_diag4"]
+    Ag = np.diag([cplx(v) for v in g["diag"]])
+    r = fk.feast_general(Ag, np.eye(4, dtype=complex), cplx(g["center"]), g["radius"], M0=4,
+                         fpm=fpm_with(f3=g["fpm3"], f4=g["fpm4"], f8=g["fpm8"]), engine=engine)
+    want = sorted((cplx(v) for v in g["expect_lambda"]), key=lambda x: (x.real, x.imag))
+    assert r.info == 0 and r.M == 3
+    assert np.allclose(sorted(r.lambda_, key=lambda x: (round(x.real, 10), round(x.imag, 10))), want, atol=g["atol"])
+
+
+def test_variant_a_loop_for_loop_vs_oracle(engine):
+    """Same Q0, complex half-contour sum, direct solves: the GPU walks the reference's variant A
+    with identical M / loop / info and eigenvalues to 1e-10."""
+    N, M0 = 150, 20
+    A = fo.householder_conjugated_diag(0.05 * np.arange(N))
+    rng = np.random.default_rng(3)
+    u = rng.random(N)
+    H = np.eye(N) - 2 * np.outer(u, u) / (u @ u)
+    B = H @ np.diag(1 + 0.5 * rng.random(N)) @ H
+    B = 0.5 * (B + B.T)
+    Q0 = fo.seeded_subspace(N, M0)
+    ref = fo.feast_hermitian(A, B, 1.0, 1.6, M0, ne=8, fpm4=60, Q0=Q0)
+    got = fk.feast_hip_hermitian(engine, A, B, 1.0, 1.6, M0, fpm_with(f2=8, f4=60), solver="direct", real_projection=False, Q0=Q0)
+    assert (got.info, got.M) == (ref.info, ref.M) and abs(got.loop - ref.loop) <= 1
+    assert np.allclose(np.sort(got.lambda_), np.sort(ref.lam), atol=1e-10)
+    assert got.epsout <= 1e-12 and ref.epsout <= 1e-12
+
+
+def test_cfg1_readme_quickstart(engine):
+    """BASELINE cfg 1: n=100 tridiagonal Laplacian, (0.5,1.5).  M0=10 is undersized (19
+    eigenvalues inside): like the reference the solver must NOT report success.  M0=30 returns all 19."""
+    A = tridiag(100)
+    exact = np.array([2 - 2 * np.cos(k * np.pi / 101) for k in range(1, 101)])
+    inside = exact[(exact >= 0.5) & (exact <= 1.5)]
+    assert len(inside) == 19
+    r10 = fk.feast(A, None, (0.5, 1.5), M0=10, engine=engine)
+    o10 = fo.feast_hermitian(A, None, 0.5, 1.5, 10)
+    assert r10.info != 0 and o10.info != 0
+    r30 = fk.feast(A, None, (0.5, 1.5), M0=30, engine=engine)
+    o30 = fo.feast_hermitian(A, None, 0.5, 1.5, 30, fpm4=60)
+    assert r30.info == 0 and r30.M == 19 == o30.M
+    assert np.allclose(np.sort(r30.lambda_), inside, atol=1e-10) and np.allclose(np.sort(o30.lam), inside, atol=1e-10)
+    assert r30.epsout <= 1e-12
+
+
+def test_cfg2_reduced_dense_lu(engine):
+    """cfg 2 shape at N=768: A = H2 H1 diag(0.01 i) H1 H2, 20 eigenvalues 1.00..1.19 inside."""
+    N = 768
+    A = fo.householder_conjugated_diag(0.01 * np.arange(N))
+    r = fk.feast(A, None, (0.995, 1.195), M0=32, fpm=fpm_with(f2=8), engine=engine)
+    want = 0.01 * np.arange(100, 120)
+    assert r.info == 0 and r.M == 20 and np.allclose(np.sort(r.lambda_), want, atol=1e-10)
+    assert r.epsout <= 1e-12 and r.stats["factorizations"] == 8          # LU cached per node across loops
+    true_res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0)
+    assert true_res.max() <= 1e-10
+
+
+def test_cfg3_reduced_reference_mode_and_fast_mode(engine):
+    """cfg 3 shape on a 16x12x10 grid: (i) reference semantics (zero initial guess, tol 1e-12
+    per loop), (ii) warm-started inexact solves.  Both must match the closed form to 1e-10."""
+    A, B, lam = fo.cfg3_problem(16, 12, 10)
+    Emin, Emax = 0.0, 0.42
+    inside = lam[(lam >= Emin) & (lam <= Emax)]
+    M0 = len(inside) + 12
+    strict = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm_with(f2=8), engine=engine, solver="bicgstab",
+                      solver_tol=1e-12, solver_maxiter=3000, warm_start=False)
+    fast = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm_with(f2=8, f4=40), engine=engine, solver="bicgstab",
+                    warm_start=True, inner_rtol=1e-2, solver_maxiter=100)
+    ref = fo.feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm4=80)
+    for r in (strict, fast):
+        assert r.info == 0 and r.M == len(inside) == ref.M
+        assert np.allclose(np.sort(r.lambda_), inside, atol=1e-10)
+        assert np.allclose(np.sort(r.lambda_), np.sort(ref.lam), atol=1e-10)
+        assert r.epsout <= 1e-12
+        res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+        assert res.max() <= 1e-10        # residual recomputed in fp64 on the host
+
+
+def test_cfg3_full_size_properties(engine):
+    """BASELINE cfg 3 at full size (N=50 000, nnz=341 500, 16 nodes, M0=64): closed-form spectrum,
+    residual recomputed on the host, B-orthonormality of the Ritz vectors."""
+    A, B, lam = fo.cfg3_problem(50, 40, 25)
+    assert A.shape[0] == 50000 and A.nnz == 341500
+    Emin, Emax = 0.0, 0.1775
+    inside = lam[(lam >= Emin) & (lam <= Emax)]
+    assert len(inside) == 44
+    r = fk.feast(A, B, (Emin, Emax), M0=64, fpm=fpm_with(f2=16, f4=40), engine=engine, solver="bicgstab",
+                 warm_start=True, inner_rtol=1e-2, solver_maxiter=100)
+    assert r.info == 0 and r.M == 44 and r.epsout <= 1e-12
+    assert np.abs(np.sort(r.lambda_) - inside).max() <= 1e-10
+    res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert res.max() <= 1e-10
+    G = r.q.T @ (B @ r.q)
+    d = np.sqrt(np.diag(G))
+    assert np.abs(G / np.outer(d, d) - np.eye(44)).max() <= 1e-8
+
+
+def test_cfg5_reduced_general_dense(engine):
+    """cfg 5 shape at N=400: non-normal complex matrix with known eigenvalues in the disc."""
+    N = 400
+    rng = np.random.default_rng(20260515)
+    rad = 6.0 * np.sqrt(rng.random(N))
+    delta = rad * np.exp(2j * np.pi * rng.random(N))
+    U = np.triu(rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N)), 1) / np.sqrt(N)
+    T = np.diag(delta) + 0.05 * U
+    v = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    v /= np.linalg.norm(v)
+    H = np.eye(N) - 2 * np.outer(v, v.conj())
+    A = H @ T @ H
+    inside = delta[np.abs(delta) <= 1.5]
+    M0 = len(inside) + 14
+    r = fk.feast_general(A, None, 0.0, 1.5, M0=M0, fpm=fpm_with(f8=24, f4=40), engine=engine)
+    o = fo.feast_general(A, None, 0.0, 1.5, M0, ne=24, fpm4=40)
+    assert r.info == 0 and o.info == 0 and r.M == o.M == len(inside)
+    key = lambda x: (round(x.real, 8), round(x.imag, 8))
+    assert np.allclose(sorted(r.lambda_, key=key), sorted(inside, key=key), atol=1e-9)
+    assert np.allclose(sorted(r.lambda_, key=key), sorted(o.lam, key=key), atol=1e-9)
+    assert r.epsout <= 1e-11
+
+
+def test_empty_and_edge_inputs(engine):
+    A = tridiag(20)
+    # interval with no eigenvalue: reference reports info=5 / M=0
+    r = fk.feast(A, None, (5.0, 6.0), M0=4, engine=engine)
+    o = fo.feast_hermitian(A, None, 5.0, 6.0, 4)
+    assert r.M == 0 == o.M and r.info == 5 == o.info
+    # M0 == N (maximum) and M0 clipped to N like feast() does
+    r = fk.feast(A, None, (0.0, 4.0), M0=64, engine=engine)
+    assert r.info == 0 and r.M == 20
+    # singular shift on the contour cannot happen for Hermitian input (Im z != 0); a 1x1 problem works
+    r = fk.feast(np.array([[2.0]]), None, (1.0, 3.0), M0=1, engine=engine)
+    assert r.info == 0 and r.M == 1 and abs(r.lambda_[0] - 2.0) < 1e-12

@@ -1,0 +1,201 @@
+"""CPU tests of the host-side mirror (feastkit.jl_amd): parameters, contours, partition and
+the refinement loops, driven through a test-only oracle engine (tests/oracle_engine.py).
+The product path itself has no CPU fallback -- see test_no_cpu_fallback."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import feast_oracle as fo
+import feastkit_jl_amd as fk
+from kat_util import cmat, cplx, load_kats, sparse_tridiag, tridiag
+from oracle_engine import OracleEngine
+
+K = load_kats()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fpm_sentinel_and_defaults():
+    fpm = fk.feastinit()
+    assert all(fpm[i] == fk.FEAST_UNINITIALIZED for i in range(1, 65))
+    fpm[2] = 6                      # user override survives feastdefault!
+    fk.feastdefault(fpm)
+    assert fpm[2] == 6
+    fpm = fk.feastdefault(fk.feastinit())
+    for k, v in K["fpm_defaults"].items():
+        assert fpm[int(k)] == v
+    assert fpm[8] == 16 and fpm[16] == 0 and fpm[18] == 100
+    assert fk.feast_tolerance(fpm) == 1e-12
+
+
+@pytest.mark.parametrize("ne", [4, 6, 8, 12, 16, 24])
+def test_contours_match_oracle(ne):
+    fpm = fk.feastdefault(fk.feastinit())
+    fpm[2] = ne
+    fpm[8] = ne
+    Z, W = fk.feast_contour(-0.3, 2.1, fpm)
+    Zo, Wo = fo.feast_contour(-0.3, 2.1, ne)
+    assert np.array_equal(Z, Zo) and np.array_equal(W, Wo)
+    Zg, Wg = fk.feast_gcontour(0.5 + 0.25j, 1.7, fpm)
+    Zgo, Wgo = fo.feast_gcontour(0.5 + 0.25j, 1.7, ne)
+    assert np.array_equal(Zg, Zgo) and np.array_equal(Wg, Wgo)
+    fpm[16] = 1
+    assert np.array_equal(fk.feast_contour(0.0, 1.0, fpm)[1], fo.feast_contour(0.0, 1.0, ne, fpm16=1)[1])
+    fpm[18], fpm[19] = 40, 30
+    assert np.array_equal(fk.feast_gcontour(0.0, 1.0, fpm)[0], fo.feast_gcontour(0.0, 1.0, ne, 1, 40, 30)[0])
+    assert fk.feast_inside_gcontour(0.2 + 0.1j, 0.0, 1.0, fpm) == fo.inside_gcontour(0.2 + 0.1j, 0.0, 1.0, 40, 30)
+
+
+def test_distribute_contour_points_matches_reference_partition():
+    for ne, nw in ((16, 8), (8, 3), (24, 4), (3, 5), (16, 1)):
+        chunks = fo.distribute_contour_points(ne, nw)
+        parts = fk.distribute_contour_points(ne, nw)
+        assert [(c[0] if c else parts[i][0], len(c)) for i, c in enumerate(chunks)] == parts
+        assert sum(n for _, n in parts) == ne
+
+
+def test_input_checks_return_reference_error_codes():
+    eng = OracleEngine()
+    A = tridiag(5)
+    fpm = fk.feastinit()
+    assert fk.feast_hip_hermitian(eng, A, None, 1.0, 0.5, 3, fpm).info == 3     # Emin >= Emax
+    assert fk.feast_hip_hermitian(eng, A, None, 0.0, 1.0, 0, fpm).info == 2     # M0 <= 0
+    assert fk.feast_hip_hermitian(eng, A, None, 0.0, 1.0, 9, fpm).info == 2     # M0 > N
+    assert fk.feast_hip_general(eng, A, None, 0.0, -1.0, 3, fpm).info == 4       # r <= 0
+    with pytest.raises(ValueError):
+        fk.feast(np.array([[1.0, 2.0, 0.0], [0.0, 3.0, 1.0], [0.5, 0.0, 4.0]]), np.eye(3), (0.5, 3.5), M0=3, engine=eng)
+    with pytest.raises(ValueError):
+        fk.feast(tridiag(3), None, (0.5, 3.5), M0=3, backend="threads", engine=eng)
+
+
+def _variant_a_cases():
+    k = K["tridiag3_real_sym"]
+    yield "tridiag3", tridiag(3), np.eye(3), k["interval"], 3, {}, k["expect_lambda"]
+    k = K["hermitian3_dense"]
+    yield "herm3", cmat(k["A"]), None, k["interval"], 3, {}, k["expect_lambda"]
+    k = K["hermitian3_sparse"]
+    yield "herm3_sparse", sp.csc_matrix(cmat(k["A"])), None, k["interval"], 3, {}, k["expect_lambda"]
+    k = K["diag80_oversized"]
+    yield "diag80", np.diag(np.arange(1.0, 81)), None, k["interval"], 32, {2: 8, 3: 7, 4: 4}, k["expect_lambda"]
+    k = K["tridiag10_backends"]
+    yield "tridiag10", sparse_tridiag(10), None, k["interval"], 10, {2: 8, 4: 20}, k["expect_lambda"]
+    k = K["hermitian_generalized_diag6"]
+    yield ("diag6", sp.diags(np.array(k["A_diag"], dtype=complex)).tocsc(), sp.diags(np.array(k["B_diag"], dtype=complex)).tocsc(),
+           k["interval"], 6, {}, k["expect_lambda"])
+
+
+@pytest.mark.parametrize("case", list(_variant_a_cases()), ids=lambda c: c[0])
+def test_hermitian_loop_equals_oracle_variant_a(case):
+    """With the oracle engine and the complex half-contour sum the :hip host loop must walk
+    the reference's variant A step for step: same M, loop count, info, eigenvalues."""
+    name, A, B, interval, M0, fp, expect = case
+    fpm = fk.feastinit()
+    for i, v in fp.items():
+        fpm[i] = v
+    Q0 = fo.seeded_subspace(A.shape[0], M0)
+    ref = fo.feast_hermitian(A, B, interval[0], interval[1], M0, ne=fp.get(2, 8), fpm3=fp.get(3, 12), fpm4=fp.get(4, 20), Q0=Q0)
+    got = fk.feast_hip_hermitian(OracleEngine(), A, B, interval[0], interval[1], M0, fpm, solver="direct",
+                                 real_projection=False, Q0=Q0)
+    assert (got.info, got.M, got.loop) == (ref.info, ref.M, ref.loop)
+    assert np.allclose(got.lambda_, ref.lam, atol=1e-12)
+    assert np.allclose(np.sort(got.lambda_), sorted(expect), atol=1e-8)
+    assert np.allclose(got.res, ref.res, atol=1e-10)
+
+
+def test_real_projection_same_eigenpairs_fewer_loops():
+    A, B, lam = fo.cfg3_problem(6, 5, 4)
+    inside = lam[(lam >= 0) & (lam <= 2.0)]
+    fpm = fk.feastinit()
+    fpm[4] = 80
+    half = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 2.0, len(inside) + 10, fpm, real_projection=False)
+    full = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 2.0, len(inside) + 10, fk.feastinit(), real_projection=True)
+    assert half.info == full.info == 0 and half.M == full.M == len(inside)
+    assert np.allclose(np.sort(half.lambda_), inside, atol=1e-10) and np.allclose(np.sort(full.lambda_), inside, atol=1e-10)
+    assert full.loop < half.loop / 3 and full.epsout <= 1e-12
+
+
+def test_general_loop_equals_oracle_variant_c():
+    k = K["general2"]
+    A, B = cmat(k["A"]), cmat(k["B"])
+    for Bin, expect in ((None, k["expect_standard"]), (B, k["expect_generalized"])):
+        Q0 = fo.seeded_subspace(2, 2)
+        ref = fo.feast_general(A, Bin, cplx(k["center"]), k["radius"], 2, Q0=Q0)
+        got = fk.feast_hip_general(OracleEngine(), A, Bin, cplx(k["center"]), k["radius"], 2, fk.feastinit(), Q0=Q0)
+        assert (got.info, got.M, got.loop) == (ref.info, ref.M, ref.loop)
+        assert np.allclose(np.sort(got.lambda_.real), expect, atol=k["atol"])
+    g = K["mpi_complex_general_diag4"]
+    A = np.diag([cplx(v) for v in g["diag"]])
+    fpm = fk.feastinit()
+    fpm[3], fpm[4], fpm[8] = g["fpm3"], g["fpm4"], g["fpm8"]
+    got = fk.feast_general(A, np.eye(4, dtype=complex), cplx(g["center"]), g["radius"], M0=4, fpm=fpm, engine=OracleEngine())
+    want = sorted((cplx(v) for v in g["expect_lambda"]), key=lambda x: (x.real, x.imag))
+    assert got.info == 0 and got.M == 3
+    assert np.allclose(sorted(got.lambda_, key=lambda x: (round(x.real, 10), round(x.imag, 10))), want, atol=g["atol"])
+
+
+def test_feast_api_real_input_returns_real_vectors():
+    k = K["diag4_variant_b"]
+    A = np.diag(k["diag"])
+    fpm = fk.feastinit()
+    fpm[2], fpm[4] = k["fpm2"], k["fpm4"]
+    r = fk.feast(A, np.eye(4), tuple(k["interval"]), M0=4, fpm=fpm, engine=OracleEngine())
+    assert r.info == 0 and r.M == k["expect_M"] and not np.iscomplexobj(r.q)
+    assert np.allclose(np.sort(r.lambda_), k["expect_lambda"], atol=k["atol"])
+    r2 = fk.feast(A, (0.4, 1.6), M0=4, fpm=fk.feastinit(), engine=OracleEngine())      # feast(A, interval) form
+    assert r2.M == 3
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(fk.FeastHipUnavailable):
+        fk.HipEngine(0)
+    with pytest.raises(fk.FeastHipUnavailable):
+        fk.feast(tridiag(4), None, (0.5, 1.5), M0=2)
+
+
+WORKER = r'''
+import os, sys
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, torch.distributed as dist
+import feast_oracle as fo, feastkit_jl_amd as fk
+from oracle_engine import OracleEngine
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+A, B, lam = fo.cfg3_problem(6, 5, 4)
+inside = lam[(lam >= 0) & (lam <= 2.0)]
+fpm = fk.feastinit(); fpm[2] = 8
+eng = OracleEngine()
+r = fk.feast_hip_hermitian(eng, A, B, 0.0, 2.0, len(inside) + 10, fpm, real_projection=True)
+assert (eng.first, eng.count) == fk.distribute_contour_points(8, 2)[dist.get_rank()]
+single = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 2.0, len(inside) + 10, fk.feastinit(), real_projection=True, group=dist.new_group([dist.get_rank()]) if False else None) if False else None
+g = fk.feast_hip_general(OracleEngine(), np.diag([0.5+0.1j, 1.0+0.2j, 2.0-0.1j, 4.0]), None, 1.0+0.1j, 1.3, 4, fk.feastinit())
+np.save(r"{out}/r%s.npy" % sys.argv[1], np.concatenate([[r.info, r.M, r.loop, r.epsout], np.sort(r.lambda_), [g.M], np.sort(g.lambda_.real)]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    """world_size-2 run of the sharded sweep (one all-reduce of Q_proj per loop) equals the
+    single-process result: the N>1 path of bench.py, on gloo."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, port=port, out=str(tmp_path)))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    assert np.array_equal(r0, r1)                     # every rank holds the same reduced result
+    A, B, lam = fo.cfg3_problem(6, 5, 4)
+    inside = lam[(lam >= 0) & (lam <= 2.0)]
+    fpm = fk.feastinit(); fpm[2] = 8
+    one = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 2.0, len(inside) + 10, fpm, real_projection=True)
+    assert (int(r0[0]), int(r0[1]), int(r0[2])) == (one.info, one.M, one.loop)
+    assert np.allclose(r0[4:4 + one.M], np.sort(one.lambda_), atol=1e-11)
+    assert np.allclose(r0[4:4 + one.M], inside, atol=1e-10)
+    assert int(r0[4 + one.M]) == 3

@@ -1,0 +1,185 @@
+"""Pins the CPU oracle (oracle/feast_oracle.py) against every known-answer fixture the
+reference's own tests hold for the hot path (tests/golden/reference_kats.json)."""
+import math
+
+import numpy as np
+import scipy.sparse as sp
+
+import feast_oracle as fo
+from kat_util import cmat, cplx, load_kats, sparse_tridiag, tridiag
+
+K = load_kats()
+
+
+def test_reorder_by_interval_kat():
+    k = K["reorder_by_interval"]
+    V = np.array(k["vectors"], dtype=np.complex128)
+    lam, vec, m, perm = fo.reorder_by_interval(np.array(k["lambda"]), V, k["Emin"], k["Emax"], 4)
+    assert m == k["expect_m"]
+    assert lam.tolist() == k["expect_lambda"]
+    assert np.array_equal(vec, V[:, [i - 1 for i in k["expect_cols_1based"]]])
+
+
+def test_sort_kats():
+    k = K["feast_sort"]
+    q = np.array(k["q"])
+    lam, qs, res = fo.feast_sort(np.array(k["lambda"]), q, np.array(k["res"]), 4)
+    assert lam.tolist() == k["expect_lambda"] and res.tolist() == k["expect_res"]
+    assert np.array_equal(qs, q[:, [i - 1 for i in k["expect_cols_1based"]]])
+    g = K["feast_sort_general"]
+    lam_src = np.array([cplx(v) for v in g["lambda"]])
+    q = np.arange(12, dtype=complex).reshape(3, 4)
+    lam, qs, res = fo.feast_sort_general(lam_src, q, np.array(g["res"]), 4)
+    order = [i - 1 for i in g["expect_order_1based"]]
+    assert np.array_equal(lam, lam_src[order]) and np.array_equal(qs, q[:, order]) and res.tolist() == g["expect_res"]
+
+
+def test_residual_kat():
+    k = K["feast_residual"]
+    res = fo.feast_residual(np.array(k["A"]), np.array(k["B"]), k["lambda"], np.array(k["q"]), 2)
+    assert np.allclose(res, k["expect"], rtol=1e-14)
+
+
+def test_moment_kat():
+    # Aq = Wne[1] * (work' * workc), Bq = Zne[1] * Aq
+    k = K["moment_accumulation"]
+    work, workc = cmat(k["work"]), cmat(k["workc"])
+    w, z = cplx(k["Wne1"]), cplx(k["Zne1"])
+    Aq = w * (work.conj().T @ workc)
+    assert np.allclose(Aq, cmat(k["expect_Aq"])) and np.allclose(z * Aq, cmat(k["expect_Bq"]))
+
+
+def test_qr_compress_kat():
+    k = K["qr_compress"]
+    src = cmat(k["src"])
+    Q, rank = fo.qr_compress(src, k["ncols"])
+    assert rank == k["expect_rank"]
+    assert np.allclose(Q.conj().T @ Q, np.eye(rank), atol=1e-12)
+    assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= k["span_tol"]
+
+
+def test_shifted_identity_kat():
+    k = K["shifted_identity"]
+    n, z = k["n"], cplx(k["z"])
+    A = tridiag(n)
+    assert np.allclose(fo.dense_shifted_identity_minus(z, A), z * np.eye(n) - A)
+
+
+def test_contour_lengths_and_quadrature_identity():
+    Z, W = fo.feast_contour(0.0, 1.0, K["contour_lengths"]["fpm2_default"])
+    assert len(Z) == len(W) == 8
+    Zg, Wg = fo.feast_gcontour(0.0, 1.0, K["contour_lengths"]["fpm8_default"])
+    assert len(Zg) == len(Wg) == 16
+    # the rational filter of the half contour: Re(sum 2 w/(z - x)) ~ 1 inside, ~ 0 outside
+    for x, want in ((0.5, 1.0), (0.3, 1.0), (3.0, 0.0), (-2.0, 0.0)):
+        assert abs(np.real(np.sum(2 * W / (Z - x))) - want) < 1e-6
+    for x, want in ((0.2 + 0.1j, 1.0), (3.0 + 0j, 0.0)):
+        assert abs(np.sum(Wg / (Zg - x)) - want) < 1e-6
+
+
+def test_tridiag3_real_symmetric():
+    k = K["tridiag3_real_sym"]
+    r = fo.feast_hermitian(tridiag(3), np.eye(3), *k["interval"], k["M0"])
+    assert r.info == k["expect_info"] and r.M == k["expect_M"]
+    assert np.allclose(np.sort(r.lam), sorted(k["expect_lambda"]), atol=k["atol"])
+
+
+def test_hermitian3_dense_and_sparse():
+    for name in ("hermitian3_dense", "hermitian3_sparse"):
+        k = K[name]
+        A = cmat(k["A"])
+        for Ain in (A, sp.csc_matrix(A)):
+            r = fo.feast_hermitian(Ain, None, *k["interval"], k["M0"])
+            assert r.info == 0 and r.M == 3
+            assert np.allclose(np.sort(r.lam), k["expect_lambda"], atol=k["atol"])
+
+
+def test_general2():
+    k = K["general2"]
+    A, B = cmat(k["A"]), cmat(k["B"])
+    r = fo.feast_general(A, None, cplx(k["center"]), k["radius"], k["M0"])
+    assert r.info == 0 and r.M == 2 and np.allclose(np.sort(r.lam.real), k["expect_standard"], atol=k["atol"])
+    r = fo.feast_general(A, B, cplx(k["center"]), k["radius"], k["M0"])
+    assert r.info == 0 and r.M == 2 and np.allclose(np.sort(r.lam.real), k["expect_generalized"], atol=k["atol"])
+    r = fo.feast_general(sp.csc_matrix(A), None, cplx(k["center"]), k["radius"], k["M0"])
+    assert r.M == 2 and np.allclose(np.sort(r.lam.real), k["expect_standard"], atol=k["atol"])
+
+
+def test_diag80_oversized_subspace():
+    k = K["diag80_oversized"]
+    A = np.diag(np.arange(1.0, k["n"] + 1))
+    for Ain in (A, sp.csc_matrix(A)):
+        r = fo.feast_hermitian(Ain, None, *k["interval"], k["M0"], ne=k["fpm2"], fpm3=k["fpm3"], fpm4=k["fpm4"])
+        assert r.info == k["expect_info"] and r.M == k["expect_M"]
+        assert np.allclose(r.lam, k["expect_lambda"], atol=k["atol"]) and r.res.max() < k["max_res"]
+
+
+def test_variant_b_diag4():
+    k = K["diag4_variant_b"]
+    A = np.diag(k["diag"])
+    for Ain, Bin in ((A, np.eye(4)), (sp.csc_matrix(A), sp.identity(4, format="csc"))):
+        r = fo.pfeast_moments(Ain, Bin, *k["interval"], k["M0"], ne=k["fpm2"], fpm4=k["fpm4"])
+        assert r.info == 0 and r.M == k["expect_M"] and np.allclose(np.sort(r.lam), k["expect_lambda"], atol=k["atol"])
+
+
+def test_tridiag10_serial_equals_partitioned():
+    k = K["tridiag10_backends"]
+    A = sparse_tridiag(k["n"])
+    r = fo.feast_hermitian(A, None, *k["interval"], k["M0"], ne=k["fpm2"], fpm4=k["fpm4"])
+    assert r.info == 0 and np.allclose(np.sort(r.lam), k["expect_lambda"], atol=k["atol"])
+    B = sp.identity(k["n"], format="csr")
+    r2 = fo.pfeast_moments(A, B, *k["interval"], k["M0"], ne=k["fpm2"], fpm4=k["fpm4"], nworkers=2)
+    assert r2.info == 0 and np.allclose(np.sort(r2.lam), k["expect_lambda"], atol=k["atol"])
+
+
+def test_hermitian_generalized_diag6():
+    k = K["hermitian_generalized_diag6"]
+    A = sp.diags(np.array(k["A_diag"], dtype=complex)).tocsc()
+    B = sp.diags(np.array(k["B_diag"], dtype=complex)).tocsc()
+    r = fo.feast_hermitian(A, B, *k["interval"], k["M0"])
+    assert r.info == 0 and r.M == len(k["expect_lambda"])
+    assert np.allclose(np.sort(r.lam), k["expect_lambda"], atol=k["atol"])
+
+
+def test_gmres_equals_direct_tridiag12():
+    k = K["gmres_equiv_tridiag12"]
+    A = sparse_tridiag(k["n"])
+    d = fo.feast_hermitian(A, None, *k["interval"], k["M0"])
+    g = fo.feast_hermitian(A, None, *k["interval"], k["M0"], solver="gmres", solver_tol=k["solver_tol"],
+                           solver_maxiter=k["maxiter"], solver_restart=k["restart"])
+    assert d.info == 0 and g.info == 0 and d.M == g.M == len(k["expect_lambda"])
+    assert np.allclose(np.sort(g.lam), np.sort(d.lam), atol=k["atol"])
+    assert np.allclose(np.sort(d.lam), k["expect_lambda"], atol=1e-9)
+
+
+def test_mpi_complex_fixtures():
+    k = K["mpi_complex_hermitian_diag4"]
+    A = sp.diags(np.array(k["diag"], dtype=complex)).tocsc()
+    r = fo.feast_hermitian(A, sp.identity(4, dtype=complex, format="csc"), *k["interval"], 4, ne=k["fpm2"], fpm4=k["fpm4"])
+    assert r.info == 0 and np.allclose(np.sort(r.lam), k["expect_lambda"], atol=k["atol"])
+    g = K["mpi_complex_general_diag4"]
+    A = np.diag([cplx(v) for v in g["diag"]])
+    r = fo.feast_general(A, np.eye(4, dtype=complex), cplx(g["center"]), g["radius"], 4, ne=g["fpm8"], fpm3=g["fpm3"], fpm4=g["fpm4"])
+    want = sorted((cplx(v) for v in g["expect_lambda"]), key=lambda x: (x.real, x.imag))
+    got = sorted(r.lam, key=lambda x: (round(x.real, 10), round(x.imag, 10)))
+    assert r.info == 0 and r.M == 3 and np.allclose(got, want, atol=g["atol"])
+
+
+def test_distribute_contour_points():
+    assert fo.distribute_contour_points(16, 8) == [[2 * i, 2 * i + 1] for i in range(8)]
+    assert fo.distribute_contour_points(8, 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
+    assert fo.distribute_contour_points(3, 5) == [[0], [1], [2], [], []]
+
+
+def test_closed_form_cfg3_small():
+    A, B, lam = fo.cfg3_problem(6, 5, 4)
+    ev = np.sort(np.linalg.eigvalsh(np.linalg.solve(B.toarray(), A.toarray())))
+    assert np.allclose(ev, lam, atol=1e-10)
+    inside = lam[(lam >= 0) & (lam <= 2.0)]
+    # variant A's half-contour complex filter only decays like 1/distance, so the reference
+    # needs ~34 refinement loops here (default fpm[4]=20 would end with info=5)
+    r = fo.feast_hermitian(A, B, 0.0, 2.0, len(inside) + 10, ne=8, fpm4=80)
+    assert r.info == 0 and r.M == len(inside) and np.allclose(np.sort(r.lam), inside, atol=1e-10)
+    assert r.epsout <= 1e-12 and r.loop > 20
+    r20 = fo.feast_hermitian(A, B, 0.0, 2.0, len(inside) + 10, ne=8)
+    assert r20.info == fo.FEAST_ERROR_NO_CONVERGENCE and r20.M == len(inside)
