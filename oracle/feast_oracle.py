@@ -368,8 +368,15 @@ def _is_sparse(M):
 
 def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18=100,
                     solver="direct", solver_tol=0.0, solver_maxiter=500, solver_restart=30,
-                    Q0=None, seed=20260515, contour=None, collect=None):
+                    Q0=None, seed=20260515, contour=None, collect=None, real_projection=False):
     """Variant A.  A (and B or None) dense ndarray or scipy sparse, Hermitian.
+
+    real_projection=False is the reference as written (complex half-contour sum).  True
+    takes Q_proj = Re(sum 2 w_e Y_e) -- the full-contour FEAST filter that the reference's
+    real paths use (src/parallel/feast_parallel.jl:38-55, src/kernel/feast_kernel.jl:183-186);
+    valid for real-symmetric A, B with a real start.  The reference's variant A on a random
+    start often ends with M=0 / info=5 at loop 0 on large problems (its half-contour filter
+    decays like 1/distance), so this switch provides the working CPU answer for cfg 3.
 
     ``collect``: optional dict; when given, per-loop intermediates (Q_proj,
     rank, lambda, epsout) are appended for golden-vector generation.
@@ -451,6 +458,8 @@ def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18
             Q_proj[:, :active] += weight * Y
         if failed:
             break
+        if real_projection:
+            Q_proj = np.asfortranarray(Q_proj.real.astype(np.complex128))
 
         q_rank, rank = qr_compress(Q_proj, active)
         if rank == 0:
