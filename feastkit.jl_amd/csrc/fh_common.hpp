@@ -123,6 +123,7 @@ struct feasthip_ctx {
     std::vector<cplx> lu_z;
 
     // profiling
+    unsigned long long* d_counters = nullptr;   // [0] spmm node-launches, [1] spmm column passes
     int profiling = 0;
     std::map<std::string, fh_prof_class> prof;
     std::vector<fh_event_pair> pending_events;

@@ -14,6 +14,8 @@ struct fh_spmm_args {
     int dot_mode;
     cplx* partial1; cplx* partial2;           // [nodes][nblk][LD]
     const int* node_active;                   // may be null
+    unsigned long long* counters;             // [0] active node-launches, [1] active column x vector passes (may be null)
+    int m;                                    // active width when node_active is null
 };
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st);
 

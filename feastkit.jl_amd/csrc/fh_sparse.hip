@@ -57,6 +57,14 @@ __global__ __launch_bounds__(FH_BLOCK) void k_spmm(fh_spmm_args a) {
         }
         return;
     }
+    if (a.counters && blockIdx.x == 0 && threadIdx.x == 0) {
+        // measurement support: algorithmic work of this launch = one matrix sweep per active
+        // node plus (vector passes) x (active columns) column sweeps
+        const int cols = a.node_active ? a.node_active[node] : a.m;
+        const int passes = (a.dot_mode == 1 || a.Bvec) ? 3 : 2;
+        atomicAdd(a.counters + 0, 1ull);
+        atomicAdd(a.counters + 1, (unsigned long long)(cols * passes));
+    }
     constexpr int RPW = 64 / LD;             // rows per wave pass
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

@@ -74,7 +74,8 @@ def _reduced_hermitian_eig(Sq, Aq):
 
 def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
-                        real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None):
+                        real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
+                        preloaded=False, node_assignment="block"):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -103,7 +104,8 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
 
     t_setup = time.perf_counter()
-    engine.set_problem(A, B)
+    if not preloaded:                            # matrices already resident on the device
+        engine.set_problem(A, B)
     if contour is None:
         Zne, Wne = feast_contour(Emin, Emax, fpm)
     else:

@@ -366,6 +366,13 @@ def _is_sparse(M):
     return sp.issparse(M)
 
 
+def _splu(S):
+    """SuperLU with a symmetric-pattern minimum-degree ordering -- the closest analogue of
+    UMFPACK's symmetric strategy that `lu(::SparseMatrixCSC)` picks for these matrices."""
+    return spla.splu(sp.csc_matrix(S), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.1,
+                     options=dict(SymmetricMode=True))
+
+
 def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18=100,
                     solver="direct", solver_tol=0.0, solver_maxiter=500, solver_restart=30,
                     Q0=None, seed=20260515, contour=None, collect=None, real_projection=False):
@@ -428,7 +435,7 @@ def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18
                     if factor_cache[e] is None:
                         if sparse:
                             S = (z * sp.identity(N, dtype=np.complex128, format="csc") - A) if Bc is None else (z * Bc - A)
-                            factor_cache[e] = spla.splu(sp.csc_matrix(S))
+                            factor_cache[e] = _splu(S)
                         else:
                             S = dense_shifted_identity_minus(z, A) if Bc is None else z * Bc - A
                             factor_cache[e] = sla.lu_factor(S)
