@@ -349,13 +349,6 @@ extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, dou
 // ---------------------------------------------------------------------------------------
 // operator application on panels (sparse or dense):  Y = (cb*B + ca*A) X  per column
 // ---------------------------------------------------------------------------------------
-static int fh_spmm_nblk(int N, int nodes) {
-    int nb = (N + 15) / 16;
-    int cap = 2048 / (nodes < 1 ? 1 : (nodes > 8 ? 8 : nodes));
-    if (nb > cap) nb = cap;
-    if (nb < 8) nb = 8;
-    return (nb + 7) / 8 * 8;
-}
 
 struct fh_op_call {
     const cplx* X; size_t x_stride;
@@ -367,6 +360,7 @@ struct fh_op_call {
     const int* node_active;
     int nodes;
     int m = FH_MAX_LD;     // active columns (measurement only)
+    int uniform_coef = 0;  // coefA/coefB identical across columns
 };
 
 // returns number of blocks used in x (needed to size / read partials)
@@ -379,12 +373,11 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = c.Bvec; a.b_node_stride = c.b_stride;
         a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
         a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
-        a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m;
-        int nblk = fh_spmm_nblk(a.N, c.nodes);
+        a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m; a.uniform_coef = c.uniform_coef;
         fh_prof_begin(h, "spmm");
-        fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, nblk, h->stream);
+        fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, fh_spmm_grid(a.N, ld), h->stream);
         fh_prof_end(h);
-        return nblk;
+        return fh_spmm_partials(a.N, ld);     // partial-sum rows per node
     }
     fh_dense_op_args a;
     a.A = h->dense.A; a.B = h->dense.B; a.N = (int)h->dense.N; a.is_complex = h->dense.is_complex;
@@ -399,8 +392,8 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
     return nblk;
 }
 
-static int fh_op_nblk(feasthip_ctx* h, int nodes = 1) {
-    return h->kind == 2 ? fh_spmm_nblk((int)h->csr.N, nodes) : fh_dense_op_nblk((int)h->dense.N);
+static int fh_op_nblk(feasthip_ctx* h, int ld) {
+    return h->kind == 2 ? fh_spmm_partials((int)h->csr.N, ld) : fh_dense_op_nblk((int)h->dense.N);
 }
 static int64_t fh_N(feasthip_ctx* h) { return h->kind == 2 ? h->csr.N : h->dense.N; }
 static bool fh_b_identity(feasthip_ctx* h) { return h->kind == 2 ? h->csr.b_identity != 0 : h->dense.b_identity != 0; }
@@ -459,7 +452,7 @@ static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vec
     if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
     s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
     int* d_count = s.node_active + nodes;
-    const int nblk_op = fh_op_nblk(h, nodes);
+    const int nblk_op = fh_op_nblk(h, ld);
     const int nblk_vec = fh_kry_nblk(N, ld, nodes);
     const int nblk_max = std::max(nblk_op, nblk_vec);
     if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
@@ -487,6 +480,7 @@ static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vec
     // R = RHS - S X0, ||R||^2
     fh_op_call oc;
     oc.m = m;
+    oc.uniform_coef = 1;        // S_e = z_e B - A for every column
     oc.X = X; oc.x_stride = stride; oc.Y = R; oc.y_stride = panel; oc.coefA = dca; oc.coefB = dcb;
     oc.Bvec = RHS; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 3;
     oc.partial1 = part1; oc.partial2 = part2; oc.node_active = nullptr; oc.nodes = nodes;
@@ -898,7 +892,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
     cplx* Rp = (cplx*)p;
     if ((rc = fh_get_buf(h, "rz_V", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
     cplx* dV = (cplx*)p;
-    const int nblk_op = fh_op_nblk(h), nblk_vec = fh_vec_nblk(N, ld);
+    const int nblk_op = fh_op_nblk(h, ld), nblk_vec = fh_vec_nblk(N, ld);
     if ((rc = fh_get_buf(h, "rz_part", (size_t)std::max(nblk_op, nblk_vec) * ld * sizeof(cplx), &p))) return rc;
     cplx* part = (cplx*)p;
     if ((rc = fh_get_buf(h, "rz_dots", (size_t)ld * sizeof(cplx), &p))) return rc;

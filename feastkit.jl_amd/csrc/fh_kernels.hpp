@@ -16,7 +16,10 @@ struct fh_spmm_args {
     const int* node_active;                   // may be null
     unsigned long long* counters;             // [0] active node-launches, [1] active column x vector passes (may be null)
     int m;                                    // active width when node_active is null
+    int uniform_coef;                         // coefA/coefB identical for every column of a node
 };
+int fh_spmm_grid(int N, int ld);
+int fh_spmm_partials(int N, int ld);
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st);
 
 // ---- BiCGStab vector kernels -----------------------------------------------------------

@@ -43,84 +43,181 @@ __device__ __forceinline__ void fh_block_reduce_cols(cplx v, cplx* red, cplx* ou
 //            1: partial1 = <U, Y>                 (BiCGStab sigma = <rhat, v>)
 //            2: partial1 = <Y, Xown>, partial2 = <Y, Y>   (omega = <t,s>/<t,t>)
 //            3: partial2 = <Y, Y>                 (residual norms)
-// Mapping: a wave covers 64/LD rows x LD columns; each block owns a contiguous row chunk.
+//
+// Locality design (measured on cfg 3 with rocprofv3 FETCH_SIZE: a one-row-per-wave kernel
+// over all 64 columns re-fetched every gathered X row ~5x from beyond L2 -- 5.2 GB per launch
+// against 1.75 GB algorithmic):
+//   * persistent 1-D grid of 8*S workgroups; block b belongs to XCD group (b & 7).  Each XCD
+//     group owns ONE 16-column tile of the panel (256 B per row) and one slice of the rows
+//     (8/NT slices), so a gathered X line is only ever wanted by one private L2;
+//   * inside a group the S workgroups sweep the slice as a moving band of S*16 consecutive
+//     rows, so the X lines live in L2 for the stencil reuse distance only (band + halo,
+//     ~1.5 MB at cfg 3) and every X line is fetched from HBM once;
+//   * streaming operands (U, Bvec in; Y out) use non-temporal accesses so they do not evict
+//     the X window or the CSR slice;
+//   * a wave covers 4 rows x 16 columns; the 16 lanes of a row load 16 nonzeros' column
+//     index / A / B values in one coalesced access and broadcast them with shuffles.  When the
+//     coefficient pair is the same for every column (the shifted operator z B - A) the loading
+//     lane forms s = cb*b + ca*a once per nonzero.
+// Placement (which XCD a block lands on) only affects speed, never results.
 // ------------------------------------------------------------------------------------
+static inline int fh_spmm_slots(int N, int ld) {
+    const int nt = ld / 16, slices = 8 / nt;
+    int rows = (N + slices - 1) / slices;
+    int S = (rows + 15) / 16;
+    if (S > 128) S = 128;     // 8*S <= 1024 workgroups, all co-resident at 4 waves/SIMD
+    if (S < 1) S = 1;
+    return S;
+}
+int fh_spmm_grid(int N, int ld) { return 8 * fh_spmm_slots(N, ld); }
+// number of partial-sum rows per node the finalize kernels must add up
+int fh_spmm_partials(int N, int ld) { return (8 / (ld / 16)) * fh_spmm_slots(N, ld); }
+
+__device__ __forceinline__ double fh_shfl16(double v, int src) { return __shfl(v, src, 16); }
+__device__ __forceinline__ cplx fh_shfl16(cplx v, int src) { return cmake(__shfl(v.x, src, 16), __shfl(v.y, src, 16)); }
+__device__ __forceinline__ double fh_vzero(double) { return 0.0; }
+__device__ __forceinline__ cplx fh_vzero(cplx) { return cmake(0, 0); }
+__device__ __forceinline__ cplx fh_ld_nt(const cplx* p) {
+    cplx r;
+    r.x = __builtin_nontemporal_load(&p->x);
+    r.y = __builtin_nontemporal_load(&p->y);
+    return r;
+}
+__device__ __forceinline__ void fh_st_nt(cplx* p, cplx v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+}
+
 template <typename VT, int LD, bool BIDENT>
-__global__ __launch_bounds__(FH_BLOCK) void k_spmm(fh_spmm_args a) {
-    const int node = blockIdx.y;
-    if (a.node_active && a.node_active[node] == 0) {
-        // still have to publish zero partials so the finalize kernels read defined data
-        if (a.dot_mode != 0 && threadIdx.x < LD) {
-            size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD + threadIdx.x;
-            if (a.partial1) a.partial1[o] = cmake(0, 0);
-            if (a.partial2) a.partial2[o] = cmake(0, 0);
-        }
-        return;
-    }
-    if (a.counters && blockIdx.x == 0 && threadIdx.x == 0) {
-        // measurement support: algorithmic work of this launch = one matrix sweep per active
-        // node plus (vector passes) x (active columns) column sweeps
-        const int cols = a.node_active ? a.node_active[node] : a.m;
-        const int passes = (a.dot_mode == 1 || a.Bvec) ? 3 : 2;
-        atomicAdd(a.counters + 0, 1ull);
-        atomicAdd(a.counters + 1, (unsigned long long)(cols * passes));
-    }
-    constexpr int RPW = 64 / LD;             // rows per wave pass
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int c = lane % LD;
-    const int rsub = lane / LD;
-    const int vb = fh_virtual_block(blockIdx.x, gridDim.x);
-    const int rows_per_block = (a.N + gridDim.x - 1) / gridDim.x;
-    const int row_begin = vb * rows_per_block;
-    const int row_end = min(a.N, row_begin + rows_per_block);
+__global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
+    constexpr int NT = LD / 16;          // column tiles
+    constexpr int SLICES = 8 / NT;       // row slices
+    __shared__ cplx red[FH_BLOCK];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int S = gridDim.x >> 3;
+    const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = grp % NT, slice = grp / NT;
+    const int slice_rows = (a.N + SLICES - 1) / SLICES;
+    const int row_lo = min(a.N, slice * slice_rows);
+    const int row_hi = min(a.N, row_lo + slice_rows);
+    const int band = S * 16;
+    const int c = ct * 16 + l16;
+    const VT* __restrict__ aval = (const VT*)a.aval;
+    const VT* __restrict__ bval = (const VT*)a.bval;
+    const int* __restrict__ rowptr = a.rowptr;
+    const int* __restrict__ colidx = a.col;
+    const int prow = slice * S + slot;                   // partial-sum row of this block
+    const int nprow = SLICES * S;
 
-    const cplx* X = a.X + (size_t)node * a.x_node_stride;
-    cplx* Y = a.Y + (size_t)node * a.y_node_stride;
-    const cplx* Bv = a.Bvec ? a.Bvec + (size_t)node * a.b_node_stride : nullptr;
-    const cplx* U = a.U ? a.U + (size_t)node * a.u_node_stride : nullptr;
-    const cplx ca = a.coefA[node * LD + c];
-    const cplx cb = a.coefB[node * LD + c];
-    const VT* aval = (const VT*)a.aval;
-    const VT* bval = (const VT*)a.bval;
-
-    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
-    for (int i = row_begin + wave * RPW + rsub; i < row_end; i += (FH_BLOCK / 64) * RPW) {
-        const int k0 = a.rowptr[i], k1 = a.rowptr[i + 1];
-        cplx acc = cmake(0, 0);
-        cplx xown = cmake(0, 0);
-        if (BIDENT || a.dot_mode == 2) xown = X[(size_t)i * LD + c];
-        if (BIDENT) acc = cmul(cb, xown);        // B = I contributes cb * x_i
-        for (int k = k0; k < k1; ++k) {
-            const int j = a.col[k];
-            const cplx x = X[(size_t)j * LD + c];
-            cplx s = vmul(aval[k], ca);
-            if (!BIDENT) s = cadd(s, vmul(bval[k], cb));
-            cfma(acc, s, x);
+    for (int node = 0; node < a.nodes; ++node) {
+        const size_t pbase = ((size_t)node * nprow + prow) * LD + ct * 16;
+        if (a.node_active && a.node_active[node] == 0) {
+            if (a.dot_mode != 0 && t < 16) {
+                if (a.partial1) a.partial1[pbase + t] = cmake(0, 0);
+                if (a.partial2) a.partial2[pbase + t] = cmake(0, 0);
+            }
+            continue;
         }
-        if (Bv) acc = csub(Bv[(size_t)i * LD + c], acc);
-        Y[(size_t)i * LD + c] = acc;
-        if (a.dot_mode == 1) {
-            cplx u = U[(size_t)i * LD + c];
-            d1 = cadd(d1, cmulc(u, acc));
-        } else if (a.dot_mode == 2) {
-            d1 = cadd(d1, cmulc(acc, xown));
-            d2.x += cabs2(acc);
-        } else if (a.dot_mode == 3) {
-            d2.x += cabs2(acc);
+        if (a.counters && blockIdx.x == 0 && t == 0) {
+            // measurement support: one matrix sweep per active node plus
+            // (vector passes) x (active columns) column sweeps
+            const int cols = a.node_active ? a.node_active[node] : a.m;
+            const int passes = (a.dot_mode == 1 || a.Bvec) ? 3 : 2;
+            atomicAdd(a.counters + 0, 1ull);
+            atomicAdd(a.counters + 1, (unsigned long long)(cols * passes));
         }
-    }
-    if (a.dot_mode != 0) {
-        __shared__ cplx red[FH_BLOCK];
-        size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
-        if (a.dot_mode == 1 || a.dot_mode == 2) fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
-        if (a.dot_mode == 2 || a.dot_mode == 3) fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+        const cplx* __restrict__ X = a.X + (size_t)node * a.x_node_stride;
+        cplx* __restrict__ Y = a.Y + (size_t)node * a.y_node_stride;
+        const cplx* __restrict__ Bv = a.Bvec ? a.Bvec + (size_t)node * a.b_node_stride : nullptr;
+        const cplx* __restrict__ U = a.U ? a.U + (size_t)node * a.u_node_stride : nullptr;
+        const cplx ca = a.coefA[node * LD + c];
+        const cplx cb = a.coefB[node * LD + c];
+        cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+        for (int i = row_lo + slot * 16 + wave * 4 + g; i < row_hi; i += band) {
+            const int k0 = rowptr[i], k1 = rowptr[i + 1];
+            cplx acc = cmake(0, 0);
+            cplx xown = cmake(0, 0);
+            if (BIDENT || a.dot_mode == 2) xown = X[(size_t)i * LD + c];
+            if (BIDENT) acc = cmul(cb, xown);            // B = I contributes cb * x_i
+            for (int kb = k0; kb < k1; kb += 16) {
+                const int kk = kb + l16;
+                const bool in = kk < k1;
+                const int mycol = in ? colidx[kk] : 0;
+                const VT mya = in ? aval[kk] : fh_vzero(VT());
+                VT myb = fh_vzero(VT());
+                if (!BIDENT) myb = in ? bval[kk] : fh_vzero(VT());
+                cplx mys = cmake(0, 0);
+                if (a.uniform_coef) {                     // same (ca, cb) in every lane of the row
+                    mys = vmul(mya, ca);
+                    if (!BIDENT) mys = cadd(mys, vmul(myb, cb));
+                }
+                const int cnt = min(16, k1 - kb);
+                // batches of 8 nonzeros: issue all gathers first, then the FMAs.  Slots past the
+                // row end carry a zero coefficient and gather the row's own (cached) line.
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += 8) {
+                    if (q0 >= cnt) break;
+                    cplx xs[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = (q0 + q < cnt) ? __shfl(mycol, q0 + q, 16) : i;
+                        xs[q] = X[(size_t)j * LD + c];
+                    }
+                    if (a.uniform_coef) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) cfma(acc, fh_shfl16(mys, q0 + q), xs[q]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            cplx sc = vmul(fh_shfl16(mya, q0 + q), ca);      // zero beyond the row end
+                            if (!BIDENT) sc = cadd(sc, vmul(fh_shfl16(myb, q0 + q), cb));
+                            cfma(acc, sc, xs[q]);
+                        }
+                    }
+                }
+            }
+            if (Bv) acc = csub(fh_ld_nt(Bv + (size_t)i * LD + c), acc);
+            fh_st_nt(Y + (size_t)i * LD + c, acc);
+            if (a.dot_mode == 1) {
+                d1 = cadd(d1, cmulc(fh_ld_nt(U + (size_t)i * LD + c), acc));
+            } else if (a.dot_mode == 2) {
+                d1 = cadd(d1, cmulc(acc, xown));
+                d2.x += cabs2(acc);
+            } else if (a.dot_mode == 3) {
+                d2.x += cabs2(acc);
+            }
+        }
+        if (a.dot_mode != 0) {
+            // per-column block reduction: 16 threads (4 waves x 4 row groups) share a column
+            if (a.dot_mode == 1 || a.dot_mode == 2) {
+                red[t] = d1;
+                __syncthreads();
+                if (t < 16) {
+                    cplx s = cmake(0, 0);
+                    for (int k = 0; k < 16; ++k) s = cadd(s, red[t + 16 * k]);
+                    a.partial1[pbase + t] = s;
+                }
+                __syncthreads();
+            }
+            if (a.dot_mode == 2 || a.dot_mode == 3) {
+                red[t] = d2;
+                __syncthreads();
+                if (t < 16) {
+                    cplx s = cmake(0, 0);
+                    for (int k = 0; k < 16; ++k) s = cadd(s, red[t + 16 * k]);
+                    a.partial2[pbase + t] = s;
+                }
+                __syncthreads();
+            }
+        }
     }
 }
 
 template <typename VT, int LD>
 static void launch_spmm_ld(const fh_spmm_args& a, bool bident, int nblk, hipStream_t st) {
-    dim3 grid(nblk, a.nodes), block(FH_BLOCK);
+    dim3 grid(nblk), block(FH_BLOCK);
     if (bident)
         hipLaunchKernelGGL((k_spmm<VT, LD, true>), grid, block, 0, st, a);
     else

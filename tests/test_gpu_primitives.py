@@ -185,6 +185,7 @@ def test_contour_apply_matches_oracle_sum(engine):
     Zne, Wne = fo.feast_contour(-1.0, 1.0, 8)
     engine.set_problem(A, B)
     engine.set_contour(Zne, Wne, 2.0)
+    engine.set_real_projection(False)      # complex half-contour sum (the session engine is shared)
     engine.set_solver("direct")
     Q = rand_block(N, m, 1, cplx=False)
     dP, status, stats, zAq, zSq = engine.contour_apply(engine.upload(Q), m, None, want_moments=True)
