@@ -113,7 +113,8 @@ def main():
         fpm = fk.feastinit()
         fpm[2], fpm[4] = 16, 40
         return fk.feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver="bicgstab", warm_start=True,
-                                      inner_rtol=args.inner_rtol, solver_maxiter=args.maxit, preloaded=True)
+                                      inner_rtol=args.inner_rtol, solver_maxiter=args.maxit, preloaded=True,
+                                      node_assignment="balanced")
 
     def fence():
         if world > 1:
@@ -171,7 +172,7 @@ def main():
         "config": {"workload": "cfg3: N=50000 sparse symmetric generalized (3-D Laplacian 50x40x25, B=I+0.1A), "
                                "interval (0,0.1775), 16 Gauss nodes, M0=64, tol 1e-12",
                    "solver": "batched BiCGStab, warm-started from Ritz pairs, inner rtol %g, <=%d its/loop" % (args.inner_rtol, args.maxit),
-                   "parallelism": "nodes/%d" % world},
+                   "parallelism": "nodes/%d (near-axis nodes paired with far-axis nodes per GPU), 1 all-reduce of Q_proj per loop" % world},
         "eigenpairs": int(res.M), "expected_eigenpairs": int(len(inside)), "max_residual": max_res,
         "max_eigenvalue_error": eig_err, "loops": int(res.loop), "converged": bool(ok),
         "krylov_iterations_per_step": int(res.stats.get("krylov_iterations", 0)),

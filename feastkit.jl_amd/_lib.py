@@ -39,6 +39,7 @@ SYMBOLS = {
     "feasthip_set_contour": (_i, [_vp, _i, _vp, _vp, _d]),
     "feasthip_set_real_projection": (_i, [_vp, _i]),
     "feasthip_set_node_range": (_i, [_vp, _i, _i]),
+    "feasthip_set_node_list": (_i, [_vp, _i, _vp]),
     "feasthip_set_solver": (_i, [_vp, _i, _d, _d, _i, _i, _i, _i]),
     "feasthip_contour_apply": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
     "feasthip_contour_apply_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),

@@ -91,3 +91,15 @@ def distribute_contour_points(ne, nw):
         out.append((start, size))
         start += size
     return out
+
+
+def balanced_contour_points(ne, nw):
+    """Node lists that pair near-axis with far-axis nodes: worker i gets nodes i, 2nw-1-i,
+    2nw+i, ... (a snake over the contour).  Krylov iteration counts grow towards the real
+    axis, so contiguous blocks (distribute_contour_points) leave one worker with all the slow
+    nodes.  Deviation from the reference partition; the reduced sum is unaffected."""
+    out = [[] for _ in range(nw)]
+    for e in range(ne):
+        r, k = divmod(e, nw)
+        out[k if r % 2 == 0 else nw - 1 - k].append(e)
+    return out

@@ -310,6 +310,8 @@ extern "C" int feasthip_set_contour(feasthip_handle h, int ne, const double* zne
     h->weight_scale = weight_scale;
     h->node_first = 0;
     h->node_count = ne;
+    h->node_ids.resize(ne);
+    for (int e = 0; e < ne; ++e) h->node_ids[e] = e;
     // cached factors belong to the old contour
     for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
     return 0;
@@ -329,6 +331,23 @@ extern "C" int feasthip_set_node_range(feasthip_handle h, int first, int count) 
     }
     h->node_first = first;
     h->node_count = count;
+    h->node_ids.resize(count);
+    for (int e = 0; e < count; ++e) h->node_ids[e] = first + e;
+    for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
+    return 0;
+}
+
+extern "C" int feasthip_set_node_list(feasthip_handle h, int count, const int* indices) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (count < 0 || (count > 0 && !indices)) { h->last_error = "feasthip_set_node_list: bad arguments"; return FEASTHIP_ERROR_FPM; }
+    for (int e = 0; e < count; ++e)
+        if (indices[e] < 0 || indices[e] >= (int)h->zne.size()) {
+            h->last_error = "feasthip_set_node_list: index outside the contour";
+            return FEASTHIP_ERROR_FPM;
+        }
+    h->node_ids.assign(indices, indices + count);
+    h->node_first = count > 0 ? indices[0] : 0;
+    h->node_count = count;
     for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
     return 0;
 }
@@ -336,7 +355,7 @@ extern "C" int feasthip_set_node_range(feasthip_handle h, int first, int count) 
 extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit, int restart,
                                    int factor_precision, int cache_factors) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
-    if (kind < 0 || kind > 2 || rtol < 0 || atol < 0 || maxit <= 0 || restart < 0 ||
+    if (kind < 0 || kind > 3 || rtol < 0 || atol < 0 || maxit <= 0 || restart < 0 ||
         (factor_precision != 64 && factor_precision != 32)) {
         h->last_error = "feasthip_set_solver: invalid option";
         return FEASTHIP_ERROR_FPM;
@@ -562,6 +581,110 @@ static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vec
 }
 
 // ---------------------------------------------------------------------------------------
+// batched COCG on panels (complex-symmetric S = zB - A only: real-symmetric A and B)
+// ---------------------------------------------------------------------------------------
+static int fh_cocg(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
+                   cplx* X, size_t stride, fh_solve_result& res) {
+    const int N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    if (stride != panel) { h->last_error = "internal: solution stride mismatch"; return FEASTHIP_ERROR_INTERNAL; }
+    int rc;
+    void* p;
+    if ((rc = fh_get_buf(h, "kry_vecs", 6 * nodes * panel * sizeof(cplx), &p))) return rc;
+    cplx* base = (cplx*)p;
+    cplx *R = base, *P = base + 2 * nodes * panel, *Qv = base + 3 * nodes * panel;
+    const size_t nl = (size_t)nodes * ld;
+    if ((rc = fh_get_buf(h, "kry_scal_c", 4 * nl * sizeof(cplx), &p))) return rc;
+    fh_krylov_scalars s;
+    s.rho = (cplx*)p; s.alpha = s.rho + nl; s.omega = s.alpha + nl; s.beta = s.omega + nl;
+    if ((rc = fh_get_buf(h, "kry_scal_d", 3 * nl * sizeof(double), &p))) return rc;
+    s.r0norm = (double*)p; s.target = s.r0norm + nl; s.rnorm = s.target + nl;
+    if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
+    s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
+    int* d_count = s.node_active + nodes;
+    const int nblk_op = fh_op_nblk(h, ld);
+    const int nblk_vec = fh_kry_nblk(N, ld, nodes);
+    const int nblk_max = std::max(nblk_op, nblk_vec);
+    if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
+    cplx* part1 = (cplx*)p;
+    cplx* part2 = part1 + (size_t)nodes * nblk_max * ld;
+    std::vector<cplx> ca(nl), cb(nl);
+    for (int e = 0; e < nodes; ++e)
+        for (int c = 0; c < ld; ++c) { ca[e * ld + c] = cmake(-1, 0); cb[e * ld + c] = z[e]; }
+    cplx *dca, *dcb;
+    if ((rc = fh_upload_coefs(h, "kry_coefA", ca, &dca))) return rc;
+    if ((rc = fh_upload_coefs(h, "kry_coefB", cb, &dcb))) return rc;
+    int* h_count = nullptr;
+    FH_CHECK(hipHostMalloc((void**)&h_count, sizeof(int)));
+
+    fh_vec_args va;
+    memset(&va, 0, sizeof(va));
+    va.N = N; va.node_stride = panel; va.X = X; va.R = R; va.P = P; va.V = Qv; va.s = s;
+    va.partial1 = part1; va.partial2 = part2;
+    // R = RHS - S X0
+    fh_op_call oc;
+    oc.m = m; oc.uniform_coef = 1;
+    oc.X = X; oc.x_stride = panel; oc.Y = R; oc.y_stride = panel; oc.coefA = dca; oc.coefB = dcb;
+    oc.Bvec = RHS; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+    oc.partial1 = part1; oc.partial2 = part2; oc.node_active = nullptr; oc.nodes = nodes;
+    fh_apply_operator(h, ld, oc);
+    res.op_calls += 1;
+    fh_launch_cocg_init(va, ld, nblk_vec, nodes, h->stream);          // P = R, rho = r^T r, ||r||
+    fh_fin_args fa;
+    fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.nblk = nblk_vec; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
+    fh_launch_fin_cocg_init(fa, ld, nodes, h->stream);
+
+    const int check_every = 8;
+    int it = 0;
+    bool all_done = false;
+    while (it < h->maxit && !all_done) {
+        int chunk = std::min(check_every, h->maxit - it);
+        for (int k = 0; k < chunk; ++k) {
+            // Q = S P, sigma = p^T S p
+            oc.X = P; oc.Y = Qv; oc.Bvec = nullptr; oc.dot_mode = 4; oc.node_active = s.node_active;
+            int nb = fh_apply_operator(h, ld, oc);
+            fa.nblk = nb;
+            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_cocg_alpha(fa, ld, nodes, h->stream); fh_prof_end(h);
+            fh_prof_begin(h, "cocg_xr"); fh_launch_cocg_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+            fa.nblk = nblk_vec;
+            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_cocg_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
+            fh_prof_begin(h, "cocg_p"); fh_launch_cocg_p(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+            res.op_calls += 1;
+        }
+        it += chunk;
+        fh_launch_count_active(s.node_active, nodes, d_count, h->stream);
+        FH_CHECK(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        all_done = (*h_count == 0);
+    }
+    hipHostFree(h_count);
+    std::vector<int> iters(nl), status(nl), active(nl);
+    std::vector<double> rnorm(nl), r0(nl);
+    FH_CHECK(hipMemcpy(iters.data(), s.iters, nl * sizeof(int), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(status.data(), s.status, nl * sizeof(int), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(active.data(), s.active, nl * sizeof(int), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(rnorm.data(), s.rnorm, nl * sizeof(double), hipMemcpyDeviceToHost));
+    FH_CHECK(hipMemcpy(r0.data(), s.r0norm, nl * sizeof(double), hipMemcpyDeviceToHost));
+    res.status.assign(nodes, 0);
+    for (int e = 0; e < nodes; ++e) {
+        int mx = 0, st = 0;
+        for (int c = 0; c < m; ++c) {
+            int i = e * ld + c;
+            mx = std::max(mx, iters[i]);
+            if (active[i]) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
+            else if (status[i] == 8 && !(rnorm[i] <= h->atol + h->rtol * r0[i])) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
+            if (r0[i] > 0) res.max_rel_res = std::max(res.max_rel_res, rnorm[i] / r0[i]);
+        }
+        res.iters_sum += mx;
+        res.max_iters = std::max(res.max_iters, mx);
+        res.status[e] = st;
+    }
+    return 0;
+}
+
+static bool fh_is_complex_input(feasthip_ctx* h) { return h->kind == 2 ? h->csr.is_complex != 0 : h->dense.is_complex != 0; }
+
+// ---------------------------------------------------------------------------------------
 // contour sweep
 // ---------------------------------------------------------------------------------------
 static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
@@ -607,8 +730,8 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     }
     std::vector<cplx> z(nodes), w(nodes);
     for (int e = 0; e < nodes; ++e) {
-        z[e] = h->zne[h->node_first + e];
-        w[e] = cscale(h->wne[h->node_first + e], h->weight_scale);
+        z[e] = h->zne[h->node_ids[e]];
+        w[e] = cscale(h->wne[h->node_ids[e]], h->weight_scale);
     }
     if ((rc = fh_get_buf(h, "ca_Y", (size_t)nodes * panel * sizeof(cplx), &p))) return rc;
     cplx* Y = (cplx*)p;
@@ -623,7 +746,11 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
         rc = fh_dense_lu_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
         if (rc) return rc;
         if (stats) stats->factorizations = nfact;
-    } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB) {
+    } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB || h->solver == FEASTHIP_SOLVER_COCG) {
+        if (h->solver == FEASTHIP_SOLVER_COCG && fh_is_complex_input(h)) {
+            h->last_error = "solver COCG needs a complex-SYMMETRIC shifted matrix: real-symmetric A and B only";
+            return FEASTHIP_ERROR_FPM;
+        }
         // initial guess
         cplx* dz;
         if ((rc = fh_upload_coefs(h, "ca_z", z, &dz))) return rc;
@@ -640,7 +767,8 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
         va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz;
         fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
         fh_solve_result sr;
-        rc = fh_bicgstab(h, ld, m, nodes, z, Rhs, Y, panel, sr);
+        rc = h->solver == FEASTHIP_SOLVER_COCG ? fh_cocg(h, ld, m, nodes, z, Rhs, Y, panel, sr)
+                                               : fh_bicgstab(h, ld, m, nodes, z, Rhs, Y, panel, sr);
         if (rc) return rc;
         status = sr.status;
         if (stats) {
@@ -1044,10 +1172,14 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         rc = fh_dense_lu_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;
         if (stats) stats->factorizations = nfact;
-    } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB) {
+    } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB || h->solver == FEASTHIP_SOLVER_COCG) {
+        if (h->solver == FEASTHIP_SOLVER_COCG && fh_is_complex_input(h)) {
+            h->last_error = "solver COCG needs real-symmetric A and B";
+            return FEASTHIP_ERROR_FPM;
+        }
         FH_CHECK(hipMemsetAsync(Y, 0, panel * sizeof(cplx), h->stream));
         fh_solve_result sr;
-        rc = fh_bicgstab(h, ld, m, 1, z, Rhs, Y, panel, sr);
+        rc = h->solver == FEASTHIP_SOLVER_COCG ? fh_cocg(h, ld, m, 1, z, Rhs, Y, panel, sr) : fh_bicgstab(h, ld, m, 1, z, Rhs, Y, panel, sr);
         if (rc) return rc;
         status = sr.status;
         if (stats) { stats->krylov_iterations = sr.iters_sum; stats->spmm_calls = sr.op_calls; stats->max_rel_residual = sr.max_rel_res; }

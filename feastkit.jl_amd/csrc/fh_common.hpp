@@ -107,6 +107,7 @@ struct feasthip_ctx {
     double weight_scale = 2.0;
     int real_projection = 0;
     int node_first = 0, node_count = 0;
+    std::vector<int> node_ids;      // local node -> contour index (set by range or list)
 
     // solver options
     int solver = 1;

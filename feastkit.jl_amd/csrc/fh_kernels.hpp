@@ -48,6 +48,12 @@ void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st)
 void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_fin_cocg_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_fin_cocg_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
+void fh_launch_fin_cocg_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st);
 
 // ---- block (panel) operations ------------------------------------------------------------

@@ -43,6 +43,7 @@ __device__ __forceinline__ void fh_block_reduce_cols(cplx v, cplx* red, cplx* ou
 //            1: partial1 = <U, Y>                 (BiCGStab sigma = <rhat, v>)
 //            2: partial1 = <Y, Xown>, partial2 = <Y, Y>   (omega = <t,s>/<t,t>)
 //            3: partial2 = <Y, Y>                 (residual norms)
+//            4: partial1 = Xown^T Y  (unconjugated; COCG sigma = p^T S p)
 //
 // Locality design (measured on cfg 3 with rocprofv3 FETCH_SIZE: a one-row-per-wave kernel
 // over all 64 columns re-fetched every gathered X row ~5x from beyond L2 -- 5.2 GB per launch
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
             const int k0 = rowptr[i], k1 = rowptr[i + 1];
             cplx acc = cmake(0, 0);
             cplx xown = cmake(0, 0);
-            if (BIDENT || a.dot_mode == 2) xown = X[(size_t)i * LD + c];
+            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4) xown = X[(size_t)i * LD + c];
             if (BIDENT) acc = cmul(cb, xown);            // B = I contributes cb * x_i
             for (int kb = k0; kb < k1; kb += 16) {
                 const int kk = kb + l16;
@@ -187,11 +188,13 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 d2.x += cabs2(acc);
             } else if (a.dot_mode == 3) {
                 d2.x += cabs2(acc);
+            } else if (a.dot_mode == 4) {
+                d1 = cadd(d1, cmul(xown, acc));          // unconjugated p^T (S p), COCG
             }
         }
         if (a.dot_mode != 0) {
             // per-column block reduction: 16 threads (4 waves x 4 row groups) share a column
-            if (a.dot_mode == 1 || a.dot_mode == 2) {
+            if (a.dot_mode == 1 || a.dot_mode == 2 || a.dot_mode == 4) {
                 red[t] = d1;
                 __syncthreads();
                 if (t < 16) {
@@ -478,6 +481,154 @@ __global__ void k_count_active(const int* node_active, int nodes, int* out) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// COCG (conjugate orthogonal CG) for COMPLEX SYMMETRIC shifted systems: real-symmetric (or
+// complex-symmetric) A, B with a complex shift give S = zB - A = S^T, so the BiCG recurrences
+// collapse to one operator application per iteration with the unconjugated bilinear form.
+// Per iteration: 1 SpMM (2 panel passes) + 6 + 3 vector passes, against 2 SpMM + 14 for BiCGStab.
+// ------------------------------------------------------------------------------------
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_init(fh_vec_args a) {
+    // P = R ; partial1 = sum R*R (unconjugated), partial2 = sum |R|^2
+    const int node = blockIdx.y;
+    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+    const size_t total = (size_t)a.N * LD;
+    const cplx* R = a.R + (size_t)node * a.node_stride;
+    cplx* P = a.P + (size_t)node * a.node_stride;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx r = R[e];
+        P[e] = r;
+        d1 = cadd(d1, cmul(r, r));
+        d2.x += cabs2(r);
+    }
+    __shared__ cplx red[FH_BLOCK];
+    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
+    // X += alpha P ; R -= alpha Q (Q stored in V) ; partial1 = sum R*R, partial2 = sum |R|^2
+    const int node = blockIdx.y;
+    const int c = threadIdx.x % LD;
+    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
+    if (on) {
+        const size_t total = (size_t)a.N * LD;
+        const cplx alpha = a.s.alpha[node * LD + c];
+        const cplx* P = a.P + (size_t)node * a.node_stride;
+        const cplx* Q = a.V + (size_t)node * a.node_stride;
+        cplx* X = a.X + (size_t)node * a.node_stride;
+        cplx* R = a.R + (size_t)node * a.node_stride;
+        for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+            cplx x = X[e];
+            cfma(x, alpha, P[e]);
+            X[e] = x;
+            cplx r = csub(R[e], cmul(alpha, Q[e]));
+            R[e] = r;
+            d1 = cadd(d1, cmul(r, r));
+            d2.x += cabs2(r);
+        }
+    }
+    __shared__ cplx red[FH_BLOCK];
+    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_p(fh_vec_args a) {
+    // P = R + beta P
+    const int node = blockIdx.y;
+    if (a.s.node_active[node] == 0) return;
+    const int c = threadIdx.x % LD;
+    if (!a.s.active[node * LD + c]) return;
+    const size_t total = (size_t)a.N * LD;
+    const cplx beta = a.s.beta[node * LD + c];
+    const cplx* R = a.R + (size_t)node * a.node_stride;
+    cplx* P = a.P + (size_t)node * a.node_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
+        P[e] = cadd(R[e], cmul(beta, P[e]));
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_init(fh_fin_args a) {
+    __shared__ cplx red[FH_FIN_BLOCK];
+    __shared__ int cnt;
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (t == 0) cnt = 0;
+    cplx rho = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
+    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        double rn = sqrt(rr.x);
+        a.s.r0norm[i] = rn;
+        a.s.rnorm[i] = rn;
+        double target = a.atol + a.rtol * rn;
+        a.s.target[i] = target;
+        a.s.rho[i] = rho;
+        a.s.alpha[i] = cmake(0, 0);
+        a.s.beta[i] = cmake(0, 0);
+        a.s.iters[i] = 0;
+        int act = (t < a.m) && (rn > target) && isfinite(rn);
+        a.s.active[i] = act;
+        a.s.status[i] = (t < a.m && !isfinite(rn)) ? 8 : 0;
+        if (act) atomicAdd(&cnt, 1);
+    }
+    __syncthreads();
+    if (t == 0) a.s.node_active[node] = cnt;
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_alpha(fh_fin_args a) {
+    // alpha = rho / (p^T S p)
+    __shared__ cplx red[FH_FIN_BLOCK];
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (a.s.node_active[node] == 0) return;
+    cplx sigma = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        if (a.s.active[i]) {
+            cplx al = cdiv(a.s.rho[i], sigma);
+            if (cabs2(sigma) == 0.0 || !fh_finite(al)) { a.s.active[i] = 0; a.s.status[i] = 8; al = cmake(0, 0); }
+            a.s.alpha[i] = al;
+        }
+    }
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_rho(fh_fin_args a) {
+    // rho_new = r^T r ; beta = rho_new / rho ; convergence bookkeeping
+    __shared__ cplx red[FH_FIN_BLOCK];
+    __shared__ int cnt;
+    const int node = blockIdx.x, t = threadIdx.x;
+    if (a.s.node_active[node] == 0) return;
+    if (t == 0) cnt = 0;
+    cplx rho_new = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
+    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
+    if (t < LD) {
+        const int i = node * LD + t;
+        if (a.s.active[i]) {
+            double rn = sqrt(rr.x);
+            a.s.rnorm[i] = rn;
+            a.s.iters[i] += 1;
+            int act = 1;
+            if (!(rn > a.s.target[i])) { act = 0; a.s.status[i] = 0; }
+            else if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
+            else {
+                cplx beta = cdiv(rho_new, a.s.rho[i]);
+                if (cabs2(a.s.rho[i]) == 0.0 || !fh_finite(beta)) { act = 0; a.s.status[i] = 8; }
+                else { a.s.beta[i] = beta; a.s.rho[i] = rho_new; }
+            }
+            a.s.active[i] = act;
+            if (act) atomicAdd(&cnt, 1);
+        }
+    }
+    __syncthreads();
+    if (t == 0) a.s.node_active[node] = cnt;
+}
+
 #define FH_DISPATCH_LD(ld, KERNEL, grid, st, args)                                         \
     do {                                                                                    \
         if ((ld) == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(FH_BLOCK), 0, st, args); \
@@ -520,4 +671,23 @@ void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st) 
 }
 void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st) {
     hipLaunchKernelGGL(k_count_active, dim3(1), dim3(64), 0, st, node_active, nodes, out);
+}
+
+void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_cocg_init, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_cocg_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_LD(ld, k_cocg_p, dim3(nblk, nodes), st, a);
+}
+void fh_launch_fin_cocg_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_FIN(ld, k_fin_cocg_init, dim3(nodes), st, a);
+}
+void fh_launch_fin_cocg_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_FIN(ld, k_fin_cocg_alpha, dim3(nodes), st, a);
+}
+void fh_launch_fin_cocg_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
+    FH_DISPATCH_FIN(ld, k_fin_cocg_rho, dim3(nodes), st, a);
 }

@@ -18,9 +18,9 @@ from . import _lib
 from ._lib import FeastHipStats, FeastHipUnavailable
 from .types import FeastHipError
 
-SOLVER_LU, SOLVER_BICGSTAB, SOLVER_GMRES = 0, 1, 2
+SOLVER_LU, SOLVER_BICGSTAB, SOLVER_GMRES, SOLVER_COCG = 0, 1, 2, 3
 _SOLVER_CODES = {"direct": SOLVER_LU, "lu": SOLVER_LU, "bicgstab": SOLVER_BICGSTAB,
-                 "iterative": SOLVER_BICGSTAB, "gmres": SOLVER_GMRES}
+                 "iterative": SOLVER_BICGSTAB, "gmres": SOLVER_GMRES, "cocg": SOLVER_COCG}
 MAX_BLOCK = 64   # FH_MAX_LD: widest panel the kernels take in one call
 
 
@@ -120,6 +120,10 @@ class HipEngine:
 
     def set_node_range(self, first, count):
         self._chk(self.lib.feasthip_set_node_range(self.h, int(first), int(count)))
+
+    def set_node_list(self, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        self._chk(self.lib.feasthip_set_node_list(self.h, len(idx), _np_ptr(idx)))
 
     def set_solver(self, solver="direct", rtol=1e-12, atol=0.0, maxit=500, restart=30,
                    factor_precision=64, cache_factors=True):

@@ -24,7 +24,7 @@ import time
 import numpy as np
 import scipy.linalg as sla
 
-from .contour import distribute_contour_points, feast_contour, feast_gcontour, feast_inside_gcontour
+from .contour import balanced_contour_points, distribute_contour_points, feast_contour, feast_gcontour, feast_inside_gcontour
 from .parameters import check_feast_srci_input, feast_tolerance, feastdefault
 from .types import FeastError, FeastResult
 
@@ -117,8 +117,13 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         real_projection = not (_isc(A) or _isc(B)) and (Q0 is None or not np.iscomplexobj(Q0) or
                                                         not np.any(np.imag(Q0)))
     engine.set_real_projection(bool(real_projection))
-    first, count = distribute_contour_points(len(Zne), world)[rank]
-    engine.set_node_range(first, count)
+    if node_assignment == "balanced" and world > 1:
+        nodes_here = balanced_contour_points(len(Zne), world)[rank]
+        engine.set_node_list(nodes_here)
+        count = len(nodes_here)
+    else:
+        first, count = distribute_contour_points(len(Zne), world)[rank]
+        engine.set_node_range(first, count)
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
                       restart=solver_restart, cache_factors=True)
     if iterative and warm_start:
@@ -137,11 +142,16 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
     ritz_lambda = None
     dX = None
     stats = {"setup_seconds": t_setup, "krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0,
-             "solve_seconds": 0.0, "loops": []}
+             "solve_seconds": 0.0, "loops": [], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
+                                                                   "project": 0.0, "eig": 0.0, "ritz": 0.0}}
+    ph = stats["phase_seconds"]
+    tick = time.perf_counter
 
     for loop_idx in range(0, maxloop + 1):
         loop_count = loop_idx
+        t_ = tick()
         dP, status, st = engine.contour_apply(dQ, active, ritz_lambda if (iterative and warm_start) else None)
+        ph["apply"] += tick() - t_
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
         stats["spmm_calls"] += st.get("spmm_calls", 0)
         stats["factorizations"] += st.get("factorizations", 0)
@@ -160,16 +170,22 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
             info = int(FeastError.Feast_ERROR_LAPACK if local_fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE)
             break
 
+        t_ = tick()
         rank_q = engine.orthonormalize(dP, active, SQRT_EPS)       # _feast_qr_compress!
+        ph["ortho"] += tick() - t_
         if rank_q == 0:
             info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
             break
+        t_ = tick()
         Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
+        ph["project"] += tick() - t_
+        t_ = tick()
         try:
             lam_red, v_red = _reduced_hermitian_eig(Sq, Aq)
         except Exception:
             info = int(FeastError.Feast_ERROR_LAPACK)
             break
+        ph["eig"] += tick() - t_
         perm, M = _reorder_by_interval(lam_red, Emin, Emax, rank_q)
         lam_sorted = lam_red[perm]
         V_sorted = np.asfortranarray(v_red[:, perm])
@@ -179,7 +195,9 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         if M == 0 and not (iterative and warm_start):
             info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
             break
+        t_ = tick()
         dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+        ph["ritz"] += tick() - t_
         lam_vec[:rank_q] = lam_sorted
         if M > 0:
             res_vec[:M] = res

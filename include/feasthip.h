@@ -54,8 +54,11 @@ enum {
     FEASTHIP_SOLVER_LU = 0,        /* :direct  -- dense only (batched complex LU)          */
     FEASTHIP_SOLVER_BICGSTAB = 1,  /* :iterative -- batched BiCGStab (Krylov.bicgstab,
                                       src/interfaces/feast_matfree.jl:716)                 */
-    FEASTHIP_SOLVER_GMRES = 2      /* :gmres   -- batched restarted GMRES(m)
+    FEASTHIP_SOLVER_GMRES = 2,     /* :gmres   -- batched restarted GMRES(m)
                                       (src/sparse/feast_sparse.jl:183-188)                 */
+    FEASTHIP_SOLVER_COCG = 3       /* conjugate-orthogonal CG for the complex-SYMMETRIC shifted
+                                      systems that real-symmetric A, B produce (one operator
+                                      application per iteration); not in the reference      */
 };
 
 enum { FEASTHIP_STORAGE_CSR = 0, FEASTHIP_STORAGE_CSC = 1 };
@@ -121,6 +124,10 @@ int  feasthip_set_real_projection(feasthip_handle h, int real_part);
  * distribute_contour_points (src/parallel/feast_parallel.jl:433-447) /
  * MPIFeastState (src/parallel/feast_mpi.jl:36-43).  Default: all nodes.              */
 int  feasthip_set_node_range(feasthip_handle h, int first, int count);
+/* Arbitrary node subset (0-based contour indices).  Used by the iterative solvers to pair
+ * near-axis (slow) with far-axis (fast) nodes per GPU instead of contiguous blocks; the
+ * summed result is independent of the assignment.                                       */
+int  feasthip_set_node_list(feasthip_handle h, int count, const int* indices);
 
 /* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
  * (src/dense/feast_dense.jl:81-84).  Iterative stop test is Krylov.jl's

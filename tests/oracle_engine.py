@@ -28,6 +28,7 @@ class OracleEngine:
         self.Zne, self.Wne, self.scale = np.array(Zne), np.array(Wne), scale
         self.ne = len(Zne)
         self.first, self.count = 0, self.ne
+        self.node_list = list(range(self.ne))
         self.factors = {}
 
     def set_real_projection(self, on):
@@ -35,6 +36,11 @@ class OracleEngine:
 
     def set_node_range(self, first, count):
         self.first, self.count = first, count
+        self.node_list = list(range(first, first + count))
+
+    def set_node_list(self, indices):
+        self.node_list = [int(i) for i in indices]
+        self.first, self.count = (self.node_list[0] if self.node_list else 0), len(self.node_list)
 
     def set_solver(self, solver="direct", **kw):
         self.solver = solver
@@ -73,7 +79,7 @@ class OracleEngine:
         Q = self.download(dQ)[:, :m]
         rhs = Q if self.B is None else self.B @ Q
         P = np.zeros((self.N, m), dtype=np.complex128)
-        for e in range(self.first, self.first + self.count):
+        for e in getattr(self, 'node_list', range(self.first, self.first + self.count)):
             P += self.scale * self.Wne[e] * self._solve(e, rhs)
         if self.real_projection:
             P = P.real.astype(np.complex128)

@@ -1,0 +1,68 @@
+"""Two ranks sharing the one GPU of the test box (gloo rendezvous, CUDA tensors): the real
+HipEngine path of the sharded sweep -- node lists per rank, all-reduce of Q_proj, redundant
+reduced eigenproblem -- must reproduce the single-rank result."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import feast_oracle as fo
+import feastkit_jl_amd as fk
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, torch, torch.distributed as dist
+import feast_oracle as fo, feastkit_jl_amd as fk
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+A, B, lam = fo.cfg3_problem(16, 12, 10)
+inside = lam[(lam >= 0) & (lam <= 0.42)]
+out = []
+for assign in ("block", "balanced"):
+    eng = fk.HipEngine(0)
+    fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 40
+    r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, len(inside) + 12, fpm, solver="bicgstab", warm_start=True,
+                               inner_rtol=1e-2, solver_maxiter=100, node_assignment=assign)
+    out += [r.info, r.M, r.epsout] + list(np.sort(r.lambda_))
+    eng.close()
+# dense LU path, general problem (full contour, 2 ranks x 8 nodes)
+Ag = np.diag([0.5+0.1j, 1.0+0.2j, 2.0-0.1j, 4.0]) + 0.01 * np.triu(np.ones((4, 4)), 1)
+eng = fk.HipEngine(0)
+g = fk.feast_hip_general(eng, Ag, None, 1.0+0.1j, 1.3, 4, fk.feastinit())
+out += [g.info, g.M] + list(np.sort(g.lambda_.real))
+np.save(r"{out}/g%d.npy" % rank, np.array(out, dtype=float))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_one_gpu_match_single_rank(engine, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, port=port, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(g0, g1)
+    A, B, lam = fo.cfg3_problem(16, 12, 10)
+    inside = lam[(lam >= 0) & (lam <= 0.42)]
+    fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 40
+    one = fk.feast_hip_hermitian(engine, A, B, 0.0, 0.42, len(inside) + 12, fpm, solver="bicgstab", warm_start=True,
+                                 inner_rtol=1e-2, solver_maxiter=100)
+    n = len(inside)
+    for off in (0, 3 + n):
+        assert (int(g0[off]), int(g0[off + 1])) == (0, n) == (one.info, one.M)
+        assert g0[off + 2] <= 1e-12
+        assert np.allclose(g0[off + 3: off + 3 + n], inside, atol=1e-10)
+        assert np.allclose(g0[off + 3: off + 3 + n], np.sort(one.lambda_), atol=1e-10)
+    off = 2 * (3 + n)
+    assert (int(g0[off]), int(g0[off + 1])) == (0, 3) and np.allclose(g0[off + 2: off + 5], [0.5, 1.0, 2.0], atol=1e-8)

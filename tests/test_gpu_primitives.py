@@ -205,3 +205,26 @@ def test_contour_apply_matches_oracle_sum(engine):
     engine.set_node_range(3, 5)
     p1 = engine.download(engine.contour_apply(engine.upload(Q), m)[0])
     assert np.abs(p0 + p1 - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("N,m", [(200, 7), (1000, 32), (3000, 64)])
+def test_cocg_shifted_solve(engine, N, m):
+    # complex-symmetric shifted system from real-symmetric A, B
+    A, B = sparse_pair(N, 5)
+    engine.set_problem(A, B)
+    engine.set_solver("cocg", rtol=1e-12, atol=0.0, maxit=4000)
+    z = -3.0 + 2.0j
+    X = rand_block(N, m, 8)
+    dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    assert rc == 0
+    Y = engine.download(dY)
+    S = (z * B - A).tocsc()
+    rel = np.linalg.norm(S @ Y - X, axis=0) / np.linalg.norm(X, axis=0)
+    assert rel.max() < 1e-10
+    # complex Hermitian input is rejected (S would not be complex symmetric)
+    Ac, Bc = sparse_pair(N, 5, cplx=True)
+    engine.set_problem(Ac, Bc)
+    import feastkit_jl_amd as fk
+    with pytest.raises(fk.FeastHipError):
+        engine.shifted_solve(z, engine.upload(X), m)
+    engine.set_solver("direct")

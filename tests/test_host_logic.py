@@ -58,6 +58,14 @@ def test_distribute_contour_points_matches_reference_partition():
         assert sum(n for _, n in parts) == ne
 
 
+def test_balanced_partition_covers_every_node_once():
+    for ne, nw in ((16, 8), (16, 4), (16, 3), (8, 2), (24, 4), (5, 8), (16, 1)):
+        parts = fk.balanced_contour_points(ne, nw)
+        assert sorted(e for p in parts for e in p) == list(range(ne))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert fk.balanced_contour_points(16, 8)[7] == [7, 8] and fk.balanced_contour_points(16, 8)[0] == [0, 15]
+
+
 def test_input_checks_return_reference_error_codes():
     eng = OracleEngine()
     A = tridiag(5)
@@ -172,6 +180,10 @@ fpm = fk.feastinit(); fpm[2] = 8
 eng = OracleEngine()
 r = fk.feast_hip_hermitian(eng, A, B, 0.0, 2.0, len(inside) + 10, fpm, real_projection=True)
 assert (eng.first, eng.count) == fk.distribute_contour_points(8, 2)[dist.get_rank()]
+eng2 = OracleEngine()
+rb = fk.feast_hip_hermitian(eng2, A, B, 0.0, 2.0, len(inside) + 10, fk.feastinit(), real_projection=True, node_assignment='balanced')
+assert eng2.node_list == fk.balanced_contour_points(8, 2)[dist.get_rank()]
+assert rb.M == r.M and np.allclose(np.sort(rb.lambda_), np.sort(r.lambda_), atol=1e-11)
 single = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 2.0, len(inside) + 10, fk.feastinit(), real_projection=True, group=dist.new_group([dist.get_rank()]) if False else None) if False else None
 g = fk.feast_hip_general(OracleEngine(), np.diag([0.5+0.1j, 1.0+0.2j, 2.0-0.1j, 4.0]), None, 1.0+0.1j, 1.3, 4, fk.feastinit())
 np.save(r"{out}/r%s.npy" % sys.argv[1], np.concatenate([[r.info, r.M, r.loop, r.epsout], np.sort(r.lambda_), [g.M], np.sort(g.lambda_.real)]))
