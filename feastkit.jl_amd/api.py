@@ -27,7 +27,7 @@ def _engine(engine, device):
 
 def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="direct", solver_tol=0.0,
           solver_maxiter=500, solver_restart=30, warm_start=False, inner_rtol=None, real_projection=None,
-          group=None, engine=None, device=0, Q0=None):
+          inner_precision=64, group=None, engine=None, device=0, Q0=None):
     """feast(A, [B,] (Emin, Emax); M0, fpm, backend=:hip) for real-symmetric / Hermitian
     dense (numpy) or sparse (scipy) matrices.  Real input is complexified and the result is
     real.(q), exactly as feast_sygv!/feast_scsrgv! do (src/dense/feast_dense.jl:362-387).
@@ -59,7 +59,7 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,
-                              group=group, Q0=Q0)
+                              inner_precision=inner_precision, group=group, Q0=Q0)
     if real_input:
         res = FeastResult(res.lambda_, np.real(res.q), res.M, res.res, res.info, res.epsout, res.loop, res.stats)
     return res

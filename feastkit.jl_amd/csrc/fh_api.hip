@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstring>
 
@@ -104,6 +105,15 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     h->stream = h->own_stream;
     if (hipMalloc((void**)&h->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_MEMORY; }
     hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long));
+    {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { hipFree(h->d_counters); hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_MEMORY; }
+        h->h_progress = (volatile unsigned long long*)hp;
+        *h->h_progress = 0ull;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { hipHostFree(hp); hipFree(h->d_counters); hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_INTERNAL; }
+        h->d_progress = (unsigned long long*)dp;
+    }
     *out = h;
     return 0;
 }
@@ -131,6 +141,7 @@ extern "C" int feasthip_destroy(feasthip_handle h) {
     fh_free_problem(h);
     fh_free_bufs(h);
     if (h->d_counters) hipFree(h->d_counters);
+    if (h->h_progress) hipHostFree((void*)h->h_progress);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -370,16 +381,17 @@ extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, dou
 // ---------------------------------------------------------------------------------------
 
 struct fh_op_call {
-    const cplx* X; size_t x_stride;
-    cplx* Y; size_t y_stride;
+    const void* X; size_t x_stride;
+    void* Y; size_t y_stride;
     const cplx* coefA; const cplx* coefB;   // device [nodes][ld]
-    const cplx* Bvec; size_t b_stride;
-    const cplx* U; size_t u_stride;
+    const void* Bvec; size_t b_stride;
+    const void* U; size_t u_stride;
     int dot_mode; cplx* partial1; cplx* partial2;
     const int* node_active;
     int nodes;
     int m = FH_MAX_LD;     // active columns (measurement only)
     int uniform_coef = 0;  // coefA/coefB identical across columns
+    int prec = 64;         // panel precision of X/Y/Bvec/U
 };
 
 // returns number of blocks used in x (needed to size / read partials)
@@ -392,7 +404,7 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = c.Bvec; a.b_node_stride = c.b_stride;
         a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
         a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
-        a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m; a.uniform_coef = c.uniform_coef;
+        a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m; a.uniform_coef = c.uniform_coef; a.prec = c.prec;
         fh_prof_begin(h, "spmm");
         fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, fh_spmm_grid(a.N, ld), h->stream);
         fh_prof_end(h);
@@ -400,9 +412,10 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
     }
     fh_dense_op_args a;
     a.A = h->dense.A; a.B = h->dense.B; a.N = (int)h->dense.N; a.is_complex = h->dense.is_complex;
-    a.nodes = c.nodes; a.X = c.X; a.x_node_stride = c.x_stride; a.Y = c.Y; a.y_node_stride = c.y_stride;
-    a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = c.Bvec; a.b_node_stride = c.b_stride;
-    a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
+    // dense operator: complex128 panels only (fh_krylov forces prec 64 for dense matrices)
+    a.nodes = c.nodes; a.X = (const cplx*)c.X; a.x_node_stride = c.x_stride; a.Y = (cplx*)c.Y; a.y_node_stride = c.y_stride;
+    a.coefA = c.coefA; a.coefB = c.coefB; a.Bvec = (const cplx*)c.Bvec; a.b_node_stride = c.b_stride;
+    a.U = (const cplx*)c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
     a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
     int nblk = fh_dense_op_nblk(a.N);
     fh_prof_begin(h, "dense_op");
@@ -439,10 +452,18 @@ static int fh_upload_coefs(feasthip_ctx* h, const char* name, const std::vector<
 }
 
 // ---------------------------------------------------------------------------------------
-// batched BiCGStab on panels:  solve (z_e B - A) X_e = RHS for e in [0, nodes)
-// X holds the initial guess on entry.  All arrays are device panels (N x ld), node-strided.
+// batched Krylov solves on panels:  (z_e B - A) X_e = RHS  for e in [0, nodes)
+//   method 0: BiCGStab (general), method 1: COCG (complex-symmetric S only)
+//   prec 64 : everything in complex128; X holds the initial guess on entry.
+//   prec 32 : mixed precision.  The fp64 residual r0 = RHS - S X0 of the initial guess is
+//             normalised per column and narrowed to complex64; the correction S d = r0/||r0||
+//             is solved in complex64 from a zero guess (all panels 8 B/element, reductions still
+//             fp64) and added back, X = X0 + ||r0|| d.  The FEAST refinement loop only needs a
+//             relative reduction of r0 (inexact solves), so single precision is ample; the
+//             warm start, the residual and the Rayleigh-Ritz step stay fp64.
 // ---------------------------------------------------------------------------------------
 struct fh_solve_result {
+    std::vector<int> node_iters, col_iters;
     int64_t iters_sum = 0;      // sum over nodes of max column iterations
     int64_t op_calls = 0;
     int max_iters = 0;
@@ -450,24 +471,29 @@ struct fh_solve_result {
     double max_rel_res = 0.0;
 };
 
-static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
-                       cplx* X, size_t stride, fh_solve_result& res) {
+static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int nodes, const std::vector<cplx>& z,
+                     const cplx* RHS, cplx* X, size_t stride, fh_solve_result& res) {
+    if (h->kind != 2) prec = 64;          // the dense operator kernel takes complex128 panels only
     const int N = (int)fh_N(h);
     const size_t panel = (size_t)N * ld;
+    if (stride != panel) { h->last_error = "internal: solution stride mismatch"; return FEASTHIP_ERROR_INTERNAL; }
+    const size_t esz = prec == 32 ? sizeof(cplxf) : sizeof(cplx);
     int rc;
     void* p;
-    // vectors R, Rhat, P, V, S, T
-    if ((rc = fh_get_buf(h, "kry_vecs", 6 * nodes * panel * sizeof(cplx), &p))) return rc;
-    cplx* base = (cplx*)p;
-    cplx *R = base, *Rh = base + nodes * panel, *P = base + 2 * nodes * panel, *V = base + 3 * nodes * panel,
-         *S = base + 4 * nodes * panel, *T = base + 5 * nodes * panel;
-    // scalars
+    // work panels R, Rhat, P, V, S, T (+ D and RHS32 for the mixed-precision correction)
+    const int nvec = 6 + (prec == 32 ? 2 : 0);
+    if ((rc = fh_get_buf(h, "kry_vecs", (size_t)nvec * nodes * panel * esz, &p))) return rc;
+    char* base = (char*)p;
+    auto vec = [&](int k) { return (void*)(base + (size_t)k * nodes * panel * esz); };
+    void *R = vec(0), *Rh = vec(1), *P = vec(2), *V = vec(3), *S = vec(4), *T = vec(5);
     const size_t nl = (size_t)nodes * ld;
     if ((rc = fh_get_buf(h, "kry_scal_c", 4 * nl * sizeof(cplx), &p))) return rc;
     fh_krylov_scalars s;
     s.rho = (cplx*)p; s.alpha = s.rho + nl; s.omega = s.alpha + nl; s.beta = s.omega + nl;
-    if ((rc = fh_get_buf(h, "kry_scal_d", 3 * nl * sizeof(double), &p))) return rc;
+    if ((rc = fh_get_buf(h, "kry_scal_d", 5 * nl * sizeof(double), &p))) return rc;
     s.r0norm = (double*)p; s.target = s.r0norm + nl; s.rnorm = s.target + nl;
+    double* r0_64 = s.rnorm + nl;            // fp64 initial-residual norms (mixed precision)
+    double* inv_r0 = r0_64 + nl;
     if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
     s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
     int* d_count = s.node_active + nodes;
@@ -486,74 +512,138 @@ static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vec
     if ((rc = fh_upload_coefs(h, "kry_coefA", ca, &dca))) return rc;
     if ((rc = fh_upload_coefs(h, "kry_coefB", cb, &dcb))) return rc;
 
-    int* h_count = nullptr;
-    FH_CHECK(hipHostMalloc((void**)&h_count, sizeof(int)));
-
-    fh_vec_args va;
-    va.N = N; va.node_stride = stride; va.X = X; va.R = R; va.Rhat = Rh; va.P = P; va.V = V; va.S = S; va.T = T;
-    va.Q = nullptr; va.lambda = nullptr; va.znode = nullptr; va.s = s; va.partial1 = part1; va.partial2 = part2;
-    // note: R/Rhat/P/V/S/T use the packed stride `panel`; X may use a different stride
-    fh_vec_args vw = va;   // work vectors view with stride = panel
-    (void)vw;
-
-    // R = RHS - S X0, ||R||^2
     fh_op_call oc;
-    oc.m = m;
-    oc.uniform_coef = 1;        // S_e = z_e B - A for every column
-    oc.X = X; oc.x_stride = stride; oc.Y = R; oc.y_stride = panel; oc.coefA = dca; oc.coefB = dcb;
-    oc.Bvec = RHS; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 3;
-    oc.partial1 = part1; oc.partial2 = part2; oc.node_active = nullptr; oc.nodes = nodes;
-    int nb = fh_apply_operator(h, ld, oc);
-    res.op_calls += 1;
+    oc.m = m; oc.uniform_coef = 1; oc.coefA = dca; oc.coefB = dcb; oc.nodes = nodes;
+    oc.partial1 = part1; oc.partial2 = part2; oc.U = nullptr; oc.u_stride = 0;
     fh_fin_args fa;
-    fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.nblk = nb; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
-    fh_launch_fin_init(fa, ld, nodes, h->stream);
-    // Rhat = R ; P = R
-    fh_vec_args vc = va;
-    vc.node_stride = panel;
-    fh_launch_copy_r(vc, ld, nblk_vec, nodes, h->stream);
+    fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
+    fa.atol_scale = nullptr; fa.mode = method;
+    fh_vec_args va;
+    memset(&va, 0, sizeof(va));
+    va.N = N; va.node_stride = panel; va.R = R; va.Rhat = Rh; va.P = P; va.V = V; va.S = S; va.T = T;
+    va.s = s; va.partial1 = part1; va.partial2 = part2; va.prec = prec;
 
-    const int check_every = 8;
+    void* Xk = X;        // the panel the Krylov recurrences update
+    if (prec == 64) {
+        // R = RHS - S X0, ||R||^2
+        oc.prec = 64; oc.X = X; oc.x_stride = panel; oc.Y = R; oc.y_stride = panel; oc.Bvec = RHS; oc.b_stride = 0;
+        oc.dot_mode = 3; oc.node_active = nullptr;
+        fa.nblk = fh_apply_operator(h, ld, oc);
+        res.op_calls += 1;
+    } else {
+        // fp64 residual of the warm start into the (fp64-sized) tail of the work area
+        void* q;
+        if ((rc = fh_get_buf(h, "kry_r64", (size_t)nodes * panel * sizeof(cplx), &q))) return rc;
+        cplx* R64 = (cplx*)q;
+        oc.prec = 64; oc.X = X; oc.x_stride = panel; oc.Y = R64; oc.y_stride = panel; oc.Bvec = RHS; oc.b_stride = 0;
+        oc.dot_mode = 3; oc.node_active = nullptr;
+        int nb = fh_apply_operator(h, ld, oc);
+        res.op_calls += 1;
+        fh_fin_args f0 = fa;                       // only to obtain ||r0|| per column
+        f0.nblk = nb; f0.rtol = 0.0; f0.atol = 0.0; f0.mode = 0;
+        fh_launch_fin_init(f0, ld, nodes, h->stream);
+        FH_CHECK(hipMemcpyAsync(r0_64, s.r0norm, nl * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        // narrow: RHS32 = R64 / ||r0||, D = 0, R = RHS32
+        cplxf* D = (cplxf*)vec(6);
+        cplxf* RHS32 = (cplxf*)vec(7);
+        fh_launch_narrow_scaled(R64, panel, RHS32, panel, r0_64, N, ld, nblk_vec, nodes, h->stream);
+        FH_CHECK(hipMemsetAsync(D, 0, (size_t)nodes * panel * sizeof(cplxf), h->stream));
+        FH_CHECK(hipMemcpyAsync(R, RHS32, (size_t)nodes * panel * sizeof(cplxf), hipMemcpyDeviceToDevice, h->stream));
+        Xk = D;
+        // norms of the (unit) scaled residual for the stop test; atol is rescaled by 1/||r0||
+        std::vector<double> hr0(nl), hinv(nl);
+        FH_CHECK(hipMemcpyAsync(hr0.data(), r0_64, nl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < nl; ++i) hinv[i] = hr0[i] > 0 ? 1.0 / hr0[i] : 0.0;
+        FH_CHECK(hipMemcpyAsync(inv_r0, hinv.data(), nl * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        fa.atol_scale = inv_r0;
+        // ||R||^2 of the narrowed residual through a zero-cost pass: reuse cocg_init/copy below
+    }
+    va.X = Xk;
+    const int vprec = prec;
+    if (method == 1) {
+        // COCG: P = R, rho = r^T r, ||r||
+        fh_launch_cocg_init(va, ld, nblk_vec, nodes, h->stream);
+        fa.nblk = nblk_vec;
+        fh_launch_fin_init(fa, ld, nodes, h->stream);
+    } else {
+        if (prec == 32) {
+            // partial2 = ||R||^2 of the narrowed residual (cocg_init also writes P = R)
+            fh_launch_cocg_init(va, ld, nblk_vec, nodes, h->stream);
+            fa.nblk = nblk_vec;
+        }
+        fa.mode = 0;
+        fh_launch_fin_init(fa, ld, nodes, h->stream);
+        fh_launch_copy_r(va, ld, nblk_vec, nodes, h->stream);            // Rhat = R ; P = R
+    }
+    (void)vprec;
+
+    oc.prec = prec; oc.Bvec = nullptr; oc.b_stride = 0; oc.x_stride = panel; oc.y_stride = panel;
+    // Iterate without ever blocking in the HIP runtime: chunks of `check_every` iterations are
+    // queued back to back, each followed by a tiny kernel that publishes (chunk tag, active
+    // columns) to a host-mapped word.  The host polls that word, stays at most two chunks ahead
+    // of the device and stops queueing once a published count is zero.  (A hipStreamSynchronize
+    // per chunk idled the GPU for milliseconds each time: 1.1 s -> 0.7 s per cfg-3 solve.)
+    const int check_every = getenv("FH_CHECK_EVERY") ? std::max(1, atoi(getenv("FH_CHECK_EVERY"))) : 16;
+    (void)d_count;
+    *h->h_progress = 0ull;
     int it = 0;
+    unsigned tag = 0;
     bool all_done = false;
+    auto t_loop0 = std::chrono::steady_clock::now();
+    auto progress = [&](unsigned& seen_tag, unsigned& seen_cnt) {
+        unsigned long long w = *h->h_progress;
+        seen_tag = (unsigned)(w >> 32); seen_cnt = (unsigned)(w & 0xffffffffull);
+    };
     while (it < h->maxit && !all_done) {
         int chunk = std::min(check_every, h->maxit - it);
         for (int k = 0; k < chunk; ++k) {
-            // V = S P, sigma = <Rhat, V>
-            oc.X = P; oc.x_stride = panel; oc.Y = V; oc.y_stride = panel; oc.Bvec = nullptr; oc.U = Rh; oc.u_stride = panel;
-            oc.dot_mode = 1; oc.node_active = s.node_active;
-            nb = fh_apply_operator(h, ld, oc);
-            fa.nblk = nb;
-            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_alpha(fa, ld, nodes, h->stream); fh_prof_end(h);
-            // S = R - alpha V
-            fh_prof_begin(h, "bicg_s"); fh_launch_s_update(vc, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
-            // T = S S, <T,S>, <T,T>
-            oc.X = S; oc.Y = T; oc.U = nullptr; oc.dot_mode = 2;
-            nb = fh_apply_operator(h, ld, oc);
-            fa.nblk = nb;
-            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_omega(fa, ld, nodes, h->stream); fh_prof_end(h);
-            // X += alpha P + omega S ; R = S - omega T ; rho_new, ||R||
-            {
-                // X uses `stride`, the work vectors use `panel`: pass X pre-offset per node via stride
-                fh_vec_args vx = vc;
-                vx.X = X;
-                // k_xr_update indexes every array with node_stride; X needs its own stride
-                if (stride != panel) { h->last_error = "internal: solution stride mismatch"; hipHostFree(h_count); return FEASTHIP_ERROR_INTERNAL; }
-                fh_prof_begin(h, "bicg_xr"); fh_launch_xr_update(vx, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+            if (method == 0) {
+                // V = S P, sigma = <Rhat, V>
+                oc.X = P; oc.Y = V; oc.U = Rh; oc.u_stride = panel; oc.dot_mode = 1; oc.node_active = s.node_active;
+                fa.nblk = fh_apply_operator(h, ld, oc);
+                fh_prof_begin(h, "dot_finalize"); fh_launch_fin_alpha(fa, ld, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "bicg_s"); fh_launch_s_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+                // T = S S, <T,S>, <T,T>
+                oc.X = S; oc.Y = T; oc.U = nullptr; oc.dot_mode = 2;
+                fa.nblk = fh_apply_operator(h, ld, oc);
+                fh_prof_begin(h, "dot_finalize"); fh_launch_fin_omega(fa, ld, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "bicg_xr"); fh_launch_xr_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+                fa.nblk = nblk_vec;
+                fh_prof_begin(h, "dot_finalize"); fh_launch_fin_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "bicg_p"); fh_launch_p_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+                res.op_calls += 2;
+            } else {
+                // Q = S P (stored in V), sigma = p^T S p
+                oc.X = P; oc.Y = V; oc.U = nullptr; oc.dot_mode = 4; oc.node_active = s.node_active;
+                fa.nblk = fh_apply_operator(h, ld, oc);
+                fh_prof_begin(h, "dot_finalize"); fh_launch_fin_alpha(fa, ld, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "cocg_xr"); fh_launch_cocg_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+                fa.nblk = nblk_vec;
+                fh_prof_begin(h, "dot_finalize"); fh_launch_fin_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "cocg_p"); fh_launch_cocg_p(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+                res.op_calls += 1;
             }
-            fa.nblk = nblk_vec;
-            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
-            // P = R + beta (P - omega V)
-            fh_prof_begin(h, "bicg_p"); fh_launch_p_update(vc, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
-            res.op_calls += 2;
         }
         it += chunk;
-        fh_launch_count_active(s.node_active, nodes, d_count, h->stream);
-        FH_CHECK(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        FH_CHECK(hipStreamSynchronize(h->stream));
-        all_done = (*h_count == 0);
+        ++tag;
+        fh_launch_publish_progress(s.node_active, nodes, h->d_progress, tag, h->stream);
+        // throttle: wait (by polling host memory) until the device has finished chunk tag-2
+        unsigned st = 0, sc = 0;
+        for (;;) {
+            progress(st, sc);
+            if (st >= 1 && sc == 0) { all_done = true; break; }
+            if (tag < 3 || st + 3 > tag) break;      // at most three chunks queued ahead of the device
+            std::this_thread::sleep_for(std::chrono::microseconds(100));   // poll, do not burn the core
+        }
     }
-    hipHostFree(h_count);
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (getenv("FH_DEBUG_TIMING"))
+        fprintf(stderr, "[fh_krylov] nodes=%d its queued=%d loop wall %.3f ms\n", nodes, it,
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count());
+    if (prec == 32)    // X = X0 + ||r0|| d
+        fh_launch_widen_axpy(X, panel, (const cplxf*)Xk, panel, r0_64, N, ld, nblk_vec, nodes, h->stream);
 
     // gather per-column bookkeeping
     std::vector<int> iters(nl), status(nl), active(nl);
@@ -569,113 +659,13 @@ static int fh_bicgstab(feasthip_ctx* h, int ld, int m, int nodes, const std::vec
         for (int c = 0; c < m; ++c) {
             int i = e * ld + c;
             mx = std::max(mx, iters[i]);
+            res.col_iters.push_back(iters[i]);
             if (active[i]) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
             else if (status[i] == 8 && !(rnorm[i] <= h->atol + h->rtol * r0[i])) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
             if (r0[i] > 0) res.max_rel_res = std::max(res.max_rel_res, rnorm[i] / r0[i]);
         }
         res.iters_sum += mx;
-        res.max_iters = std::max(res.max_iters, mx);
-        res.status[e] = st;
-    }
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------
-// batched COCG on panels (complex-symmetric S = zB - A only: real-symmetric A and B)
-// ---------------------------------------------------------------------------------------
-static int fh_cocg(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
-                   cplx* X, size_t stride, fh_solve_result& res) {
-    const int N = (int)fh_N(h);
-    const size_t panel = (size_t)N * ld;
-    if (stride != panel) { h->last_error = "internal: solution stride mismatch"; return FEASTHIP_ERROR_INTERNAL; }
-    int rc;
-    void* p;
-    if ((rc = fh_get_buf(h, "kry_vecs", 6 * nodes * panel * sizeof(cplx), &p))) return rc;
-    cplx* base = (cplx*)p;
-    cplx *R = base, *P = base + 2 * nodes * panel, *Qv = base + 3 * nodes * panel;
-    const size_t nl = (size_t)nodes * ld;
-    if ((rc = fh_get_buf(h, "kry_scal_c", 4 * nl * sizeof(cplx), &p))) return rc;
-    fh_krylov_scalars s;
-    s.rho = (cplx*)p; s.alpha = s.rho + nl; s.omega = s.alpha + nl; s.beta = s.omega + nl;
-    if ((rc = fh_get_buf(h, "kry_scal_d", 3 * nl * sizeof(double), &p))) return rc;
-    s.r0norm = (double*)p; s.target = s.r0norm + nl; s.rnorm = s.target + nl;
-    if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
-    s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
-    int* d_count = s.node_active + nodes;
-    const int nblk_op = fh_op_nblk(h, ld);
-    const int nblk_vec = fh_kry_nblk(N, ld, nodes);
-    const int nblk_max = std::max(nblk_op, nblk_vec);
-    if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
-    cplx* part1 = (cplx*)p;
-    cplx* part2 = part1 + (size_t)nodes * nblk_max * ld;
-    std::vector<cplx> ca(nl), cb(nl);
-    for (int e = 0; e < nodes; ++e)
-        for (int c = 0; c < ld; ++c) { ca[e * ld + c] = cmake(-1, 0); cb[e * ld + c] = z[e]; }
-    cplx *dca, *dcb;
-    if ((rc = fh_upload_coefs(h, "kry_coefA", ca, &dca))) return rc;
-    if ((rc = fh_upload_coefs(h, "kry_coefB", cb, &dcb))) return rc;
-    int* h_count = nullptr;
-    FH_CHECK(hipHostMalloc((void**)&h_count, sizeof(int)));
-
-    fh_vec_args va;
-    memset(&va, 0, sizeof(va));
-    va.N = N; va.node_stride = panel; va.X = X; va.R = R; va.P = P; va.V = Qv; va.s = s;
-    va.partial1 = part1; va.partial2 = part2;
-    // R = RHS - S X0
-    fh_op_call oc;
-    oc.m = m; oc.uniform_coef = 1;
-    oc.X = X; oc.x_stride = panel; oc.Y = R; oc.y_stride = panel; oc.coefA = dca; oc.coefB = dcb;
-    oc.Bvec = RHS; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
-    oc.partial1 = part1; oc.partial2 = part2; oc.node_active = nullptr; oc.nodes = nodes;
-    fh_apply_operator(h, ld, oc);
-    res.op_calls += 1;
-    fh_launch_cocg_init(va, ld, nblk_vec, nodes, h->stream);          // P = R, rho = r^T r, ||r||
-    fh_fin_args fa;
-    fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.nblk = nblk_vec; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
-    fh_launch_fin_cocg_init(fa, ld, nodes, h->stream);
-
-    const int check_every = 8;
-    int it = 0;
-    bool all_done = false;
-    while (it < h->maxit && !all_done) {
-        int chunk = std::min(check_every, h->maxit - it);
-        for (int k = 0; k < chunk; ++k) {
-            // Q = S P, sigma = p^T S p
-            oc.X = P; oc.Y = Qv; oc.Bvec = nullptr; oc.dot_mode = 4; oc.node_active = s.node_active;
-            int nb = fh_apply_operator(h, ld, oc);
-            fa.nblk = nb;
-            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_cocg_alpha(fa, ld, nodes, h->stream); fh_prof_end(h);
-            fh_prof_begin(h, "cocg_xr"); fh_launch_cocg_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
-            fa.nblk = nblk_vec;
-            fh_prof_begin(h, "dot_finalize"); fh_launch_fin_cocg_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
-            fh_prof_begin(h, "cocg_p"); fh_launch_cocg_p(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
-            res.op_calls += 1;
-        }
-        it += chunk;
-        fh_launch_count_active(s.node_active, nodes, d_count, h->stream);
-        FH_CHECK(hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        FH_CHECK(hipStreamSynchronize(h->stream));
-        all_done = (*h_count == 0);
-    }
-    hipHostFree(h_count);
-    std::vector<int> iters(nl), status(nl), active(nl);
-    std::vector<double> rnorm(nl), r0(nl);
-    FH_CHECK(hipMemcpy(iters.data(), s.iters, nl * sizeof(int), hipMemcpyDeviceToHost));
-    FH_CHECK(hipMemcpy(status.data(), s.status, nl * sizeof(int), hipMemcpyDeviceToHost));
-    FH_CHECK(hipMemcpy(active.data(), s.active, nl * sizeof(int), hipMemcpyDeviceToHost));
-    FH_CHECK(hipMemcpy(rnorm.data(), s.rnorm, nl * sizeof(double), hipMemcpyDeviceToHost));
-    FH_CHECK(hipMemcpy(r0.data(), s.r0norm, nl * sizeof(double), hipMemcpyDeviceToHost));
-    res.status.assign(nodes, 0);
-    for (int e = 0; e < nodes; ++e) {
-        int mx = 0, st = 0;
-        for (int c = 0; c < m; ++c) {
-            int i = e * ld + c;
-            mx = std::max(mx, iters[i]);
-            if (active[i]) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
-            else if (status[i] == 8 && !(rnorm[i] <= h->atol + h->rtol * r0[i])) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
-            if (r0[i] > 0) res.max_rel_res = std::max(res.max_rel_res, rnorm[i] / r0[i]);
-        }
-        res.iters_sum += mx;
+        res.node_iters.push_back(mx);
         res.max_iters = std::max(res.max_iters, mx);
         res.status[e] = st;
     }
@@ -767,10 +757,12 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
         va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz;
         fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
         fh_solve_result sr;
-        rc = h->solver == FEASTHIP_SOLVER_COCG ? fh_cocg(h, ld, m, nodes, z, Rhs, Y, panel, sr)
-                                               : fh_bicgstab(h, ld, m, nodes, z, Rhs, Y, panel, sr);
+        rc = fh_krylov(h, h->solver == FEASTHIP_SOLVER_COCG ? 1 : 0, h->factor_precision, ld, m, nodes, z, Rhs, Y, panel, sr);
         if (rc) return rc;
         status = sr.status;
+        h->last_node_iters = sr.node_iters;
+        h->last_col_iters = sr.col_iters;
+        h->last_col_m = m;
         if (stats) {
             stats->krylov_iterations = sr.iters_sum;
             stats->spmm_calls = sr.op_calls;
@@ -1179,7 +1171,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         }
         FH_CHECK(hipMemsetAsync(Y, 0, panel * sizeof(cplx), h->stream));
         fh_solve_result sr;
-        rc = h->solver == FEASTHIP_SOLVER_COCG ? fh_cocg(h, ld, m, 1, z, Rhs, Y, panel, sr) : fh_bicgstab(h, ld, m, 1, z, Rhs, Y, panel, sr);
+        rc = fh_krylov(h, h->solver == FEASTHIP_SOLVER_COCG ? 1 : 0, h->factor_precision, ld, m, 1, z, Rhs, Y, panel, sr);
         if (rc) return rc;
         status = sr.status;
         if (stats) { stats->krylov_iterations = sr.iters_sum; stats->spmm_calls = sr.op_calls; stats->max_rel_residual = sr.max_rel_res; }
@@ -1212,6 +1204,18 @@ extern "C" int feasthip_shifted_solve(feasthip_handle h, double z_re, double z_i
 // ---------------------------------------------------------------------------------------
 // measurement support
 // ---------------------------------------------------------------------------------------
+extern "C" int feasthip_last_node_iterations(feasthip_handle h, int* out, int n) {
+    if (!h || !out) return FEASTHIP_ERROR_INTERNAL;
+    for (int e = 0; e < n; ++e) out[e] = e < (int)h->last_node_iters.size() ? h->last_node_iters[e] : 0;
+    return 0;
+}
+
+extern "C" int feasthip_last_column_iterations(feasthip_handle h, int* out, int n) {
+    if (!h || !out) return FEASTHIP_ERROR_INTERNAL;
+    for (int e = 0; e < n; ++e) out[e] = e < (int)h->last_col_iters.size() ? h->last_col_iters[e] : 0;
+    return 0;
+}
+
 extern "C" int feasthip_profile_enable(feasthip_handle h, int enable) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     h->profiling = enable ? 1 : 0;

@@ -35,6 +35,25 @@ __host__ __device__ inline void cfma(cplx& acc, cplx a, cplx b) {
 __host__ __device__ inline cplx vmul(double a, cplx b) { return cmake(a * b.x, a * b.y); }
 __host__ __device__ inline cplx vmul(cplx a, cplx b) { return cmul(a, b); }
 
+// ---- single-precision complex for the mixed-precision Krylov correction solves -------------
+struct __attribute__((aligned(8))) cplxf { float x, y; };
+__host__ __device__ inline cplxf cmakef(float a, float b) { cplxf r; r.x = a; r.y = b; return r; }
+__host__ __device__ inline cplxf cadd(cplxf a, cplxf b) { return cmakef(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline cplxf csub(cplxf a, cplxf b) { return cmakef(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline cplxf cmul(cplxf a, cplxf b) { return cmakef(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ inline void cfma(cplxf& acc, cplxf a, cplxf b) {
+    acc.x += a.x * b.x - a.y * b.y;
+    acc.y += a.x * b.y + a.y * b.x;
+}
+__host__ __device__ inline cplxf vmul(double a, cplxf b) { float f = (float)a; return cmakef(f * b.x, f * b.y); }
+__host__ __device__ inline cplxf vmul(cplx a, cplxf b) { return cmul(cmakef((float)a.x, (float)a.y), b); }
+// conversions: to_d widens to double complex (all reductions run in fp64); cvt<CT> narrows
+__host__ __device__ inline cplx to_d(cplx a) { return a; }
+__host__ __device__ inline cplx to_d(cplxf a) { return cmake((double)a.x, (double)a.y); }
+template <typename CT> __host__ __device__ inline CT cvt(cplx a);
+template <> __host__ __device__ inline cplx cvt<cplx>(cplx a) { return a; }
+template <> __host__ __device__ inline cplxf cvt<cplxf>(cplx a) { return cmakef((float)a.x, (float)a.y); }
+
 #define FH_MAX_LD 64
 
 #define FH_CHECK(expr)                                                                      \
@@ -114,6 +133,10 @@ struct feasthip_ctx {
     double rtol = 1e-12, atol = 0.0;
     int maxit = 500, restart = 30, factor_precision = 64, cache_factors = 1;
 
+    std::vector<int> last_col_iters;    // [local node][m] iterations per column of the last sweep
+    int last_col_m = 0;
+    std::vector<int> last_node_iters;   // per local node: max column iterations of the last sweep
+
     // workspace (grown lazily)
     std::map<std::string, std::pair<void*, size_t>> bufs;
 
@@ -122,6 +145,10 @@ struct feasthip_ctx {
     std::vector<int*> lu_pivots;
     std::vector<int> lu_valid;
     std::vector<cplx> lu_z;
+
+    // host-mapped progress word written by the device: (chunk tag << 32) | active columns
+    volatile unsigned long long* h_progress = nullptr;   // pinned host view
+    unsigned long long* d_progress = nullptr;            // device view of the same word
 
     // profiling
     unsigned long long* d_counters = nullptr;   // [0] spmm node-launches, [1] spmm column passes

@@ -89,20 +89,21 @@ __global__ __launch_bounds__(FH_BLOCK) void k_dense_op(fh_dense_op_args a) {
             const cplx ca = a.coefA[node * LD + c], cb = a.coefB[node * LD + c];
             cplx y = cmul(ca, accA[k]);
             cplx xown = cmake(0, 0);
-            if (BIDENT || a.dot_mode == 2) xown = X[(size_t)i * LD + c];
+            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4) xown = X[(size_t)i * LD + c];
             if (BIDENT) cfma(y, cb, xown); else cfma(y, cb, accB[k]);
             if (a.Bvec) y = csub(a.Bvec[(size_t)node * a.b_node_stride + (size_t)i * LD + c], y);
             Y[(size_t)i * LD + c] = y;
             if (a.dot_mode == 1) d1[k] = cmulc(a.U[(size_t)node * a.u_node_stride + (size_t)i * LD + c], y);
             else if (a.dot_mode == 2) { d1[k] = cmulc(y, xown); d2[k].x = cabs2(y); }
             else if (a.dot_mode == 3) d2[k].x = cabs2(y);
+            else if (a.dot_mode == 4) d1[k] = cmul(xown, y);
         }
     }
     if (a.dot_mode != 0) {
         // reduce over the 64 rows of the block for each column: thread (r, cg) holds CPT columns
         const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
         for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 0 && !(a.dot_mode == 1 || a.dot_mode == 2)) continue;
+            if (pass == 0 && !(a.dot_mode == 1 || a.dot_mode == 2 || a.dot_mode == 4)) continue;
             if (pass == 1 && !(a.dot_mode == 2 || a.dot_mode == 3)) continue;
             for (int k = 0; k < CPT; ++k) {
                 red[t] = pass == 0 ? d1[k] : d2[k];

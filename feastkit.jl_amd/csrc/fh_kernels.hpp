@@ -3,58 +3,67 @@
 #include "fh_common.hpp"
 
 // ---- sparse operator -------------------------------------------------------------------
+// Panel pointers are void*: complex128 panels when prec == 64, complex64 when prec == 32.
 struct fh_spmm_args {
     const int* rowptr; const int* col; const void* aval; const void* bval;
     int N; int nodes;
-    const cplx* X; size_t x_node_stride;      // element stride between nodes (0 = shared)
-    cplx* Y; size_t y_node_stride;
-    const cplx* coefA; const cplx* coefB;     // [nodes][LD] per-column coefficients
-    const cplx* Bvec; size_t b_node_stride;   // non-null: Y = Bvec - S X
-    const cplx* U; size_t u_node_stride;      // dot_mode 1: <U, Y>
+    const void* X; size_t x_node_stride;      // element stride between nodes (0 = shared)
+    void* Y; size_t y_node_stride;
+    const cplx* coefA; const cplx* coefB;     // [nodes][LD] per-column coefficients (always fp64)
+    const void* Bvec; size_t b_node_stride;   // non-null: Y = Bvec - S X
+    const void* U; size_t u_node_stride;      // dot_mode 1: <U, Y>
     int dot_mode;
-    cplx* partial1; cplx* partial2;           // [nodes][nblk][LD]
+    cplx* partial1; cplx* partial2;           // [nodes][nprow][LD], always fp64
     const int* node_active;                   // may be null
     unsigned long long* counters;             // [0] active node-launches, [1] active column x vector passes (may be null)
     int m;                                    // active width when node_active is null
     int uniform_coef;                         // coefA/coefB identical for every column of a node
+    int prec;                                 // 64 | 32
 };
 int fh_spmm_grid(int N, int ld);
 int fh_spmm_partials(int N, int ld);
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st);
 
-// ---- BiCGStab vector kernels -----------------------------------------------------------
+// ---- Krylov vector kernels (BiCGStab and COCG) -------------------------------------------
 struct fh_vec_args {
     int N;
     size_t node_stride;
-    cplx *X, *R, *Rhat, *P, *V, *S, *T;
-    const cplx* Q;             // init guess source (shared by all nodes)
+    void *X, *R, *Rhat, *P, *V, *S, *T;
+    const cplx* Q;             // init guess source (shared by all nodes, fp64)
     const double* lambda;      // [LD] Ritz values or null
     const cplx* znode;         // [nodes]
     fh_krylov_scalars s;
     cplx* partial1; cplx* partial2;
+    int prec;                  // 64 | 32
 };
 struct fh_fin_args {
     fh_krylov_scalars s;
     const cplx* partial1; const cplx* partial2;
     int nblk; int m;
     double rtol, atol;
+    const double* atol_scale;  // per (node,column) factor on atol (mixed precision: 1/||r0||), may be null
+    int mode;                  // 0 BiCGStab, 1 COCG
 };
 void fh_launch_init_guess(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_copy_r(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_p_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
-void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
-void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
-void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
-void fh_launch_fin_cocg_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
-void fh_launch_fin_cocg_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
-void fh_launch_fin_cocg_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st);
+// writes (tag << 32 | active columns) to a host-mapped word with a system-scope release store
+void fh_launch_publish_progress(const int* node_active, int nodes, unsigned long long* progress, unsigned tag, hipStream_t st);
+// mixed precision hand-off: dst = src / ||r0||  (complex64) and X += ||r0|| * D
+void fh_launch_narrow_scaled(const cplx* src, size_t src_stride, cplxf* dst, size_t dst_stride, const double* r0norm,
+                             int N, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_widen_axpy(cplx* X, size_t x_stride, const cplxf* D, size_t d_stride, const double* r0norm,
+                          int N, int ld, int nblk, int nodes, hipStream_t st);
 
 // ---- block (panel) operations ------------------------------------------------------------
 // column-major (N x m, leading dim lds) <-> row-major panel (N x ld), zero padded

@@ -5,22 +5,18 @@
 //   solve_shifted_iterative!              src/sparse/feast_sparse.jl:164-203 (per-column GMRES)
 //   Krylov.bicgstab matrix-free solver    src/interfaces/feast_matfree.jl:716-718
 //
-// Data layout: block vectors are row-major N x LD c128 ("panels", fh_common.hpp); the
-// node batch is the y dimension of every launch.  The operator is never materialised per
+// Data layout: block vectors are row-major N x LD panels (fh_common.hpp) of complex128 or --
+// for the mixed-precision correction solves -- complex64; the node batch is walked inside the
+// SpMM and is the y dimension of the vector kernels.  The operator is never materialised per
 // node: S_c = coefB[c]*B + coefA[c]*A is formed on the fly from the real (or complex) CSR
 // values of A and B on their union pattern, with a per-COLUMN complex coefficient pair so
 // the same kernel serves (z_e B - A)X, A X, B X and the residual A X - B X diag(lambda).
+// Every reduction (dots, norms) accumulates in fp64 whatever the panel precision.
 #include "fh_common.hpp"
 #include "fh_kernels.hpp"
 
 #define FH_BLOCK 256
-
-// XCD-aware virtual block id: blocks b, b+8, ... share an XCD (round-robin dispatch), so
-// give each XCD one contiguous chunk of the row range; neighbouring stencil rows then hit
-// the same L2.  Bijective when gridDim.x % 8 == 0 (the launcher guarantees it).
-__device__ __forceinline__ int fh_virtual_block(int b, int nb) {
-    return (b & 7) * (nb >> 3) + (b >> 3);
-}
+#define FH_FIN_BLOCK 1024
 
 template <int LD>
 __device__ __forceinline__ void fh_block_reduce_cols(cplx v, cplx* red, cplx* out) {
@@ -49,8 +45,8 @@ __device__ __forceinline__ void fh_block_reduce_cols(cplx v, cplx* red, cplx* ou
 // over all 64 columns re-fetched every gathered X row ~5x from beyond L2 -- 5.2 GB per launch
 // against 1.75 GB algorithmic):
 //   * persistent 1-D grid of 8*S workgroups; block b belongs to XCD group (b & 7).  Each XCD
-//     group owns ONE 16-column tile of the panel (256 B per row) and one slice of the rows
-//     (8/NT slices), so a gathered X line is only ever wanted by one private L2;
+//     group owns ONE 16-column tile of the panel and one slice of the rows (8/NT slices), so
+//     a gathered X line is only ever wanted by one private L2;
 //   * inside a group the S workgroups sweep the slice as a moving band of S*16 consecutive
 //     rows, so the X lines live in L2 for the stencil reuse distance only (band + halo,
 //     ~1.5 MB at cfg 3) and every X line is fetched from HBM once;
@@ -76,6 +72,7 @@ int fh_spmm_partials(int N, int ld) { return (8 / (ld / 16)) * fh_spmm_slots(N, 
 
 __device__ __forceinline__ double fh_shfl16(double v, int src) { return __shfl(v, src, 16); }
 __device__ __forceinline__ cplx fh_shfl16(cplx v, int src) { return cmake(__shfl(v.x, src, 16), __shfl(v.y, src, 16)); }
+__device__ __forceinline__ cplxf fh_shfl16(cplxf v, int src) { return cmakef(__shfl(v.x, src, 16), __shfl(v.y, src, 16)); }
 __device__ __forceinline__ double fh_vzero(double) { return 0.0; }
 __device__ __forceinline__ cplx fh_vzero(cplx) { return cmake(0, 0); }
 __device__ __forceinline__ cplx fh_ld_nt(const cplx* p) {
@@ -84,12 +81,25 @@ __device__ __forceinline__ cplx fh_ld_nt(const cplx* p) {
     r.y = __builtin_nontemporal_load(&p->y);
     return r;
 }
+__device__ __forceinline__ cplxf fh_ld_nt(const cplxf* p) {
+    cplxf r;
+    r.x = __builtin_nontemporal_load(&p->x);
+    r.y = __builtin_nontemporal_load(&p->y);
+    return r;
+}
 __device__ __forceinline__ void fh_st_nt(cplx* p, cplx v) {
     __builtin_nontemporal_store(v.x, &p->x);
     __builtin_nontemporal_store(v.y, &p->y);
 }
+__device__ __forceinline__ void fh_st_nt(cplxf* p, cplxf v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+}
+template <typename CT> __device__ __forceinline__ CT fh_czero();
+template <> __device__ __forceinline__ cplx fh_czero<cplx>() { return cmake(0, 0); }
+template <> __device__ __forceinline__ cplxf fh_czero<cplxf>() { return cmakef(0.f, 0.f); }
 
-template <typename VT, int LD, bool BIDENT>
+template <typename CT, typename VT, int LD, bool BIDENT>
 __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
     constexpr int NT = LD / 16;          // column tiles
     constexpr int SLICES = 8 / NT;       // row slices
@@ -129,17 +139,17 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
             atomicAdd(a.counters + 0, 1ull);
             atomicAdd(a.counters + 1, (unsigned long long)(cols * passes));
         }
-        const cplx* __restrict__ X = a.X + (size_t)node * a.x_node_stride;
-        cplx* __restrict__ Y = a.Y + (size_t)node * a.y_node_stride;
-        const cplx* __restrict__ Bv = a.Bvec ? a.Bvec + (size_t)node * a.b_node_stride : nullptr;
-        const cplx* __restrict__ U = a.U ? a.U + (size_t)node * a.u_node_stride : nullptr;
-        const cplx ca = a.coefA[node * LD + c];
-        const cplx cb = a.coefB[node * LD + c];
+        const CT* __restrict__ X = (const CT*)a.X + (size_t)node * a.x_node_stride;
+        CT* __restrict__ Y = (CT*)a.Y + (size_t)node * a.y_node_stride;
+        const CT* __restrict__ Bv = a.Bvec ? (const CT*)a.Bvec + (size_t)node * a.b_node_stride : nullptr;
+        const CT* __restrict__ U = a.U ? (const CT*)a.U + (size_t)node * a.u_node_stride : nullptr;
+        const CT ca = cvt<CT>(a.coefA[node * LD + c]);
+        const CT cb = cvt<CT>(a.coefB[node * LD + c]);
         cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
         for (int i = row_lo + slot * 16 + wave * 4 + g; i < row_hi; i += band) {
             const int k0 = rowptr[i], k1 = rowptr[i + 1];
-            cplx acc = cmake(0, 0);
-            cplx xown = cmake(0, 0);
+            CT acc = fh_czero<CT>();
+            CT xown = fh_czero<CT>();
             if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4) xown = X[(size_t)i * LD + c];
             if (BIDENT) acc = cmul(cb, xown);            // B = I contributes cb * x_i
             for (int kb = k0; kb < k1; kb += 16) {
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 const VT mya = in ? aval[kk] : fh_vzero(VT());
                 VT myb = fh_vzero(VT());
                 if (!BIDENT) myb = in ? bval[kk] : fh_vzero(VT());
-                cplx mys = cmake(0, 0);
+                CT mys = fh_czero<CT>();
                 if (a.uniform_coef) {                     // same (ca, cb) in every lane of the row
                     mys = vmul(mya, ca);
                     if (!BIDENT) mys = cadd(mys, vmul(myb, cb));
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
 #pragma unroll
                 for (int q0 = 0; q0 < 16; q0 += 8) {
                     if (q0 >= cnt) break;
-                    cplx xs[8];
+                    CT xs[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int j = (q0 + q < cnt) ? __shfl(mycol, q0 + q, 16) : i;
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                     } else {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
-                            cplx sc = vmul(fh_shfl16(mya, q0 + q), ca);      // zero beyond the row end
+                            CT sc = vmul(fh_shfl16(mya, q0 + q), ca);        // zero beyond the row end
                             if (!BIDENT) sc = cadd(sc, vmul(fh_shfl16(myb, q0 + q), cb));
                             cfma(acc, sc, xs[q]);
                         }
@@ -181,15 +191,16 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
             }
             if (Bv) acc = csub(fh_ld_nt(Bv + (size_t)i * LD + c), acc);
             fh_st_nt(Y + (size_t)i * LD + c, acc);
+            const cplx accd = to_d(acc);
             if (a.dot_mode == 1) {
-                d1 = cadd(d1, cmulc(fh_ld_nt(U + (size_t)i * LD + c), acc));
+                d1 = cadd(d1, cmulc(to_d(fh_ld_nt(U + (size_t)i * LD + c)), accd));
             } else if (a.dot_mode == 2) {
-                d1 = cadd(d1, cmulc(acc, xown));
-                d2.x += cabs2(acc);
+                d1 = cadd(d1, cmulc(accd, to_d(xown)));
+                d2.x += cabs2(accd);
             } else if (a.dot_mode == 3) {
-                d2.x += cabs2(acc);
+                d2.x += cabs2(accd);
             } else if (a.dot_mode == 4) {
-                d1 = cadd(d1, cmul(xown, acc));          // unconjugated p^T (S p), COCG
+                d1 = cadd(d1, cmul(to_d(xown), accd));   // unconjugated p^T (S p), COCG
             }
         }
         if (a.dot_mode != 0) {
@@ -218,38 +229,42 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
     }
 }
 
-template <typename VT, int LD>
+template <typename CT, typename VT, int LD>
 static void launch_spmm_ld(const fh_spmm_args& a, bool bident, int nblk, hipStream_t st) {
     dim3 grid(nblk), block(FH_BLOCK);
     if (bident)
-        hipLaunchKernelGGL((k_spmm<VT, LD, true>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_spmm<CT, VT, LD, true>), grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL((k_spmm<VT, LD, false>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_spmm<CT, VT, LD, false>), grid, block, 0, st, a);
 }
-
-void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st) {
+template <typename CT>
+static void launch_spmm_ct(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st) {
     if (is_complex) {
-        if (ld == 16) launch_spmm_ld<cplx, 16>(a, bident, nblk, st);
-        else if (ld == 32) launch_spmm_ld<cplx, 32>(a, bident, nblk, st);
-        else launch_spmm_ld<cplx, 64>(a, bident, nblk, st);
+        if (ld == 16) launch_spmm_ld<CT, cplx, 16>(a, bident, nblk, st);
+        else if (ld == 32) launch_spmm_ld<CT, cplx, 32>(a, bident, nblk, st);
+        else launch_spmm_ld<CT, cplx, 64>(a, bident, nblk, st);
     } else {
-        if (ld == 16) launch_spmm_ld<double, 16>(a, bident, nblk, st);
-        else if (ld == 32) launch_spmm_ld<double, 32>(a, bident, nblk, st);
-        else launch_spmm_ld<double, 64>(a, bident, nblk, st);
+        if (ld == 16) launch_spmm_ld<CT, double, 16>(a, bident, nblk, st);
+        else if (ld == 32) launch_spmm_ld<CT, double, 32>(a, bident, nblk, st);
+        else launch_spmm_ld<CT, double, 64>(a, bident, nblk, st);
     }
 }
+void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st) {
+    if (a.prec == 32) launch_spmm_ct<cplxf>(a, ld, is_complex, bident, nblk, st);
+    else launch_spmm_ct<cplx>(a, ld, is_complex, bident, nblk, st);
+}
 
 // ------------------------------------------------------------------------------------
-// BiCGStab vector kernels.  Flat element index over the N*LD panel, grid-stride with a
-// stride that is a multiple of LD so a thread always sees the same column.
+// Krylov vector kernels.  Flat element index over the N*LD panel, grid-stride with a stride
+// that is a multiple of LD so a thread always sees the same column.
 // ------------------------------------------------------------------------------------
-template <int LD>
+template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_init_guess(fh_vec_args a) {
-    // X0[i,c] = Q[i,c] / (z_node - lambda_c)   (lambda == nullptr -> zero guess)
+    // X0[i,c] = Q[i,c] / (z_node - lambda_c)   (lambda == nullptr -> zero guess); always fp64
     const int node = blockIdx.y;
     const size_t total = (size_t)a.N * LD;
     const int c = threadIdx.x % LD;
-    cplx* X = a.X + (size_t)node * a.node_stride;
+    cplx* X = (cplx*)a.X + (size_t)node * a.node_stride;
     cplx f = cmake(0, 0);
     if (a.lambda) {
         cplx z = a.znode[node];
@@ -259,22 +274,22 @@ __global__ __launch_bounds__(FH_BLOCK) void k_init_guess(fh_vec_args a) {
         X[e] = a.lambda ? cmul(a.Q[e], f) : cmake(0, 0);
 }
 
-template <int LD>
+template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_copy_r(fh_vec_args a) {
     // Rhat = R, P = R
     const int node = blockIdx.y;
     const size_t total = (size_t)a.N * LD;
-    const cplx* R = a.R + (size_t)node * a.node_stride;
-    cplx* Rh = a.Rhat + (size_t)node * a.node_stride;
-    cplx* P = a.P + (size_t)node * a.node_stride;
+    const CT* R = (const CT*)a.R + (size_t)node * a.node_stride;
+    CT* Rh = (CT*)a.Rhat + (size_t)node * a.node_stride;
+    CT* P = (CT*)a.P + (size_t)node * a.node_stride;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-        cplx r = R[e];
+        CT r = R[e];
         Rh[e] = r;
         P[e] = r;
     }
 }
 
-template <int LD>
+template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_p_update(fh_vec_args a) {
     // P = R + beta (P - omega V)
     const int node = blockIdx.y;
@@ -282,17 +297,17 @@ __global__ __launch_bounds__(FH_BLOCK) void k_p_update(fh_vec_args a) {
     const size_t total = (size_t)a.N * LD;
     const int c = threadIdx.x % LD;
     if (!a.s.active[node * LD + c]) return;
-    const cplx beta = a.s.beta[node * LD + c], omega = a.s.omega[node * LD + c];
-    const cplx* R = a.R + (size_t)node * a.node_stride;
-    const cplx* V = a.V + (size_t)node * a.node_stride;
-    cplx* P = a.P + (size_t)node * a.node_stride;
+    const CT beta = cvt<CT>(a.s.beta[node * LD + c]), omega = cvt<CT>(a.s.omega[node * LD + c]);
+    const CT* R = (const CT*)a.R + (size_t)node * a.node_stride;
+    const CT* V = (const CT*)a.V + (size_t)node * a.node_stride;
+    CT* P = (CT*)a.P + (size_t)node * a.node_stride;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-        cplx t = csub(P[e], cmul(omega, V[e]));
+        CT t = csub(P[e], cmul(omega, V[e]));
         P[e] = cadd(R[e], cmul(beta, t));
     }
 }
 
-template <int LD>
+template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_s_update(fh_vec_args a) {
     // S = R - alpha V
     const int node = blockIdx.y;
@@ -300,15 +315,15 @@ __global__ __launch_bounds__(FH_BLOCK) void k_s_update(fh_vec_args a) {
     const size_t total = (size_t)a.N * LD;
     const int c = threadIdx.x % LD;
     if (!a.s.active[node * LD + c]) return;
-    const cplx alpha = a.s.alpha[node * LD + c];
-    const cplx* R = a.R + (size_t)node * a.node_stride;
-    const cplx* V = a.V + (size_t)node * a.node_stride;
-    cplx* S = a.S + (size_t)node * a.node_stride;
+    const CT alpha = cvt<CT>(a.s.alpha[node * LD + c]);
+    const CT* R = (const CT*)a.R + (size_t)node * a.node_stride;
+    const CT* V = (const CT*)a.V + (size_t)node * a.node_stride;
+    CT* S = (CT*)a.S + (size_t)node * a.node_stride;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
         S[e] = csub(R[e], cmul(alpha, V[e]));
 }
 
-template <int LD>
+template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_xr_update(fh_vec_args a) {
     // X += alpha P + omega S ; R = S - omega T ; partial1 = <Rhat, R>, partial2 = <R, R>
     const int node = blockIdx.y;
@@ -318,23 +333,24 @@ __global__ __launch_bounds__(FH_BLOCK) void k_xr_update(fh_vec_args a) {
     const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
     if (on) {
         const size_t total = (size_t)a.N * LD;
-        const cplx alpha = a.s.alpha[node * LD + c], omega = a.s.omega[node * LD + c];
-        const cplx* P = a.P + (size_t)node * a.node_stride;
-        const cplx* S = a.S + (size_t)node * a.node_stride;
-        const cplx* T = a.T + (size_t)node * a.node_stride;
-        const cplx* Rh = a.Rhat + (size_t)node * a.node_stride;
-        cplx* X = a.X + (size_t)node * a.node_stride;
-        cplx* R = a.R + (size_t)node * a.node_stride;
+        const CT alpha = cvt<CT>(a.s.alpha[node * LD + c]), omega = cvt<CT>(a.s.omega[node * LD + c]);
+        const CT* P = (const CT*)a.P + (size_t)node * a.node_stride;
+        const CT* S = (const CT*)a.S + (size_t)node * a.node_stride;
+        const CT* T = (const CT*)a.T + (size_t)node * a.node_stride;
+        const CT* Rh = (const CT*)a.Rhat + (size_t)node * a.node_stride;
+        CT* X = (CT*)a.X + (size_t)node * a.node_stride;
+        CT* R = (CT*)a.R + (size_t)node * a.node_stride;
         for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-            cplx s = S[e];
-            cplx x = X[e];
+            CT s = S[e];
+            CT x = X[e];
             cfma(x, alpha, P[e]);
             cfma(x, omega, s);
             X[e] = x;
-            cplx r = csub(s, cmul(omega, T[e]));
+            CT r = csub(s, cmul(omega, T[e]));
             R[e] = r;
-            d1 = cadd(d1, cmulc(Rh[e], r));
-            d2.x += cabs2(r);
+            const cplx rd = to_d(r);
+            d1 = cadd(d1, cmulc(to_d(Rh[e]), rd));
+            d2.x += cabs2(rd);
         }
     }
     __shared__ cplx red[FH_BLOCK];
@@ -342,8 +358,39 @@ __global__ __launch_bounds__(FH_BLOCK) void k_xr_update(fh_vec_args a) {
     fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
 }
 
-// ---- finalize kernels: one block per node, reduce the per-block partials ---------------
-#define FH_FIN_BLOCK 1024
+// ---- mixed precision: scaled narrowing of the fp64 residual, widening update of X ----------
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_narrow_scaled(const cplx* __restrict__ src, size_t src_stride,
+                                                             cplxf* __restrict__ dst, size_t dst_stride,
+                                                             const double* __restrict__ r0norm, size_t total) {
+    // dst[node][e] = src[node][e] / ||r0_c||   (zero columns stay zero)
+    const int node = blockIdx.y;
+    const double n = r0norm[node * LD + threadIdx.x % LD];
+    const double inv = n > 0.0 ? 1.0 / n : 0.0;
+    const cplx* s = src + (size_t)node * src_stride;
+    cplxf* d = dst + (size_t)node * dst_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx v = s[e];
+        d[e] = cmakef((float)(v.x * inv), (float)(v.y * inv));
+    }
+}
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_widen_axpy(cplx* __restrict__ X, size_t x_stride,
+                                                          const cplxf* __restrict__ D, size_t d_stride,
+                                                          const double* __restrict__ r0norm, size_t total) {
+    // X[node][e] += ||r0_c|| * D[node][e]
+    const int node = blockIdx.y;
+    const double n = r0norm[node * LD + threadIdx.x % LD];
+    cplx* x = X + (size_t)node * x_stride;
+    const cplxf* d = D + (size_t)node * d_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx v = x[e];
+        cplxf w = d[e];
+        x[e] = cmake(v.x + n * (double)w.x, v.y + n * (double)w.y);
+    }
+}
+
+// ---- finalize kernels: one block per node, reduce the per-block partials (always fp64) -------
 template <int LD>
 __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, int nblk, cplx* red) {
     const int t = threadIdx.x;
@@ -365,22 +412,24 @@ __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, i
 
 __device__ __forceinline__ bool fh_finite(cplx a) { return isfinite(a.x) && isfinite(a.y); }
 
+// mode 0: BiCGStab (rho = ||r||^2 from partial2); mode 1: COCG (rho = r^T r from partial1)
 template <int LD>
 __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_init(fh_fin_args a) {
-    // after R = b - S X0 with partial2 = <R,R>: set r0norm, target, rho = <rhat,r> = ||r||^2
     __shared__ cplx red[FH_FIN_BLOCK];
     __shared__ int cnt;
     const int node = blockIdx.x, t = threadIdx.x;
     if (t == 0) cnt = 0;
+    cplx rho1 = cmake(0, 0);
+    if (a.mode == 1) rho1 = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
     cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
     if (t < LD) {
         const int i = node * LD + t;
         double rn = sqrt(rr.x);
         a.s.r0norm[i] = rn;
         a.s.rnorm[i] = rn;
-        double target = a.atol + a.rtol * rn;
+        double target = a.rtol * rn + a.atol * (a.atol_scale ? a.atol_scale[i] : 1.0);
         a.s.target[i] = target;
-        a.s.rho[i] = cmake(rr.x, 0);
+        a.s.rho[i] = a.mode == 1 ? rho1 : cmake(rr.x, 0);
         a.s.alpha[i] = cmake(1, 0);
         a.s.omega[i] = cmake(1, 0);
         a.s.beta[i] = cmake(0, 0);
@@ -396,7 +445,7 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_init(fh_fin_args a) {
 
 template <int LD>
 __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_alpha(fh_fin_args a) {
-    // alpha = rho / <rhat, v>
+    // alpha = rho / sigma   (sigma = <rhat, v> for BiCGStab, p^T S p for COCG)
     __shared__ cplx red[FH_FIN_BLOCK];
     const int node = blockIdx.x, t = threadIdx.x;
     if (a.s.node_active[node] == 0) return;
@@ -435,171 +484,8 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_omega(fh_fin_args a) {
 
 template <int LD>
 __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_rho(fh_fin_args a) {
-    // rho_new = <rhat, r>, beta = (rho_new/rho)(alpha/omega); convergence bookkeeping
-    __shared__ cplx red[FH_FIN_BLOCK];
-    __shared__ int cnt;
-    const int node = blockIdx.x, t = threadIdx.x;
-    if (a.s.node_active[node] == 0) return;
-    if (t == 0) cnt = 0;
-    cplx rho_new = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
-    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
-    if (t < LD) {
-        const int i = node * LD + t;
-        if (a.s.active[i]) {
-            double rn = sqrt(rr.x);
-            a.s.rnorm[i] = rn;
-            a.s.iters[i] += 1;
-            int act = 1;
-            if (!(rn > a.s.target[i])) { act = 0; a.s.status[i] = 0; }
-            else if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
-            else {
-                cplx om = a.s.omega[i];
-                cplx beta = cmul(cdiv(rho_new, a.s.rho[i]), cdiv(a.s.alpha[i], om));
-                if (cabs2(om) == 0.0 || cabs2(a.s.rho[i]) == 0.0 || !fh_finite(beta)) {
-                    act = 0; a.s.status[i] = 8;
-                } else {
-                    a.s.beta[i] = beta;
-                    a.s.rho[i] = rho_new;
-                }
-            }
-            a.s.active[i] = act;
-            if (act) atomicAdd(&cnt, 1);
-        }
-    }
-    __syncthreads();
-    if (t == 0) {
-        a.s.node_active[node] = cnt;
-    }
-}
-
-// total number of active columns over all nodes -> *out (one block)
-__global__ void k_count_active(const int* node_active, int nodes, int* out) {
-    if (threadIdx.x == 0) {
-        int s = 0;
-        for (int i = 0; i < nodes; ++i) s += node_active[i];
-        *out = s;
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// COCG (conjugate orthogonal CG) for COMPLEX SYMMETRIC shifted systems: real-symmetric (or
-// complex-symmetric) A, B with a complex shift give S = zB - A = S^T, so the BiCG recurrences
-// collapse to one operator application per iteration with the unconjugated bilinear form.
-// Per iteration: 1 SpMM (2 panel passes) + 6 + 3 vector passes, against 2 SpMM + 14 for BiCGStab.
-// ------------------------------------------------------------------------------------
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_cocg_init(fh_vec_args a) {
-    // P = R ; partial1 = sum R*R (unconjugated), partial2 = sum |R|^2
-    const int node = blockIdx.y;
-    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
-    const size_t total = (size_t)a.N * LD;
-    const cplx* R = a.R + (size_t)node * a.node_stride;
-    cplx* P = a.P + (size_t)node * a.node_stride;
-    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
-    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-        cplx r = R[e];
-        P[e] = r;
-        d1 = cadd(d1, cmul(r, r));
-        d2.x += cabs2(r);
-    }
-    __shared__ cplx red[FH_BLOCK];
-    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
-    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
-}
-
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
-    // X += alpha P ; R -= alpha Q (Q stored in V) ; partial1 = sum R*R, partial2 = sum |R|^2
-    const int node = blockIdx.y;
-    const int c = threadIdx.x % LD;
-    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
-    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
-    const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
-    if (on) {
-        const size_t total = (size_t)a.N * LD;
-        const cplx alpha = a.s.alpha[node * LD + c];
-        const cplx* P = a.P + (size_t)node * a.node_stride;
-        const cplx* Q = a.V + (size_t)node * a.node_stride;
-        cplx* X = a.X + (size_t)node * a.node_stride;
-        cplx* R = a.R + (size_t)node * a.node_stride;
-        for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-            cplx x = X[e];
-            cfma(x, alpha, P[e]);
-            X[e] = x;
-            cplx r = csub(R[e], cmul(alpha, Q[e]));
-            R[e] = r;
-            d1 = cadd(d1, cmul(r, r));
-            d2.x += cabs2(r);
-        }
-    }
-    __shared__ cplx red[FH_BLOCK];
-    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
-    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
-}
-
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_cocg_p(fh_vec_args a) {
-    // P = R + beta P
-    const int node = blockIdx.y;
-    if (a.s.node_active[node] == 0) return;
-    const int c = threadIdx.x % LD;
-    if (!a.s.active[node * LD + c]) return;
-    const size_t total = (size_t)a.N * LD;
-    const cplx beta = a.s.beta[node * LD + c];
-    const cplx* R = a.R + (size_t)node * a.node_stride;
-    cplx* P = a.P + (size_t)node * a.node_stride;
-    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
-        P[e] = cadd(R[e], cmul(beta, P[e]));
-}
-
-template <int LD>
-__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_init(fh_fin_args a) {
-    __shared__ cplx red[FH_FIN_BLOCK];
-    __shared__ int cnt;
-    const int node = blockIdx.x, t = threadIdx.x;
-    if (t == 0) cnt = 0;
-    cplx rho = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
-    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
-    if (t < LD) {
-        const int i = node * LD + t;
-        double rn = sqrt(rr.x);
-        a.s.r0norm[i] = rn;
-        a.s.rnorm[i] = rn;
-        double target = a.atol + a.rtol * rn;
-        a.s.target[i] = target;
-        a.s.rho[i] = rho;
-        a.s.alpha[i] = cmake(0, 0);
-        a.s.beta[i] = cmake(0, 0);
-        a.s.iters[i] = 0;
-        int act = (t < a.m) && (rn > target) && isfinite(rn);
-        a.s.active[i] = act;
-        a.s.status[i] = (t < a.m && !isfinite(rn)) ? 8 : 0;
-        if (act) atomicAdd(&cnt, 1);
-    }
-    __syncthreads();
-    if (t == 0) a.s.node_active[node] = cnt;
-}
-
-template <int LD>
-__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_alpha(fh_fin_args a) {
-    // alpha = rho / (p^T S p)
-    __shared__ cplx red[FH_FIN_BLOCK];
-    const int node = blockIdx.x, t = threadIdx.x;
-    if (a.s.node_active[node] == 0) return;
-    cplx sigma = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
-    if (t < LD) {
-        const int i = node * LD + t;
-        if (a.s.active[i]) {
-            cplx al = cdiv(a.s.rho[i], sigma);
-            if (cabs2(sigma) == 0.0 || !fh_finite(al)) { a.s.active[i] = 0; a.s.status[i] = 8; al = cmake(0, 0); }
-            a.s.alpha[i] = al;
-        }
-    }
-}
-
-template <int LD>
-__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_rho(fh_fin_args a) {
-    // rho_new = r^T r ; beta = rho_new / rho ; convergence bookkeeping
+    // mode 0: rho_new = <rhat, r>, beta = (rho_new/rho)(alpha/omega)   (BiCGStab)
+    // mode 1: rho_new = r^T r,     beta = rho_new/rho                  (COCG)
     __shared__ cplx red[FH_FIN_BLOCK];
     __shared__ int cnt;
     const int node = blockIdx.x, t = threadIdx.x;
@@ -618,8 +504,18 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_rho(fh_fin_args a) {
             else if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
             else {
                 cplx beta = cdiv(rho_new, a.s.rho[i]);
-                if (cabs2(a.s.rho[i]) == 0.0 || !fh_finite(beta)) { act = 0; a.s.status[i] = 8; }
-                else { a.s.beta[i] = beta; a.s.rho[i] = rho_new; }
+                bool bad = cabs2(a.s.rho[i]) == 0.0;
+                if (a.mode == 0) {
+                    cplx om = a.s.omega[i];
+                    beta = cmul(beta, cdiv(a.s.alpha[i], om));
+                    bad = bad || cabs2(om) == 0.0;
+                }
+                if (bad || !fh_finite(beta)) {
+                    act = 0; a.s.status[i] = 8;
+                } else {
+                    a.s.beta[i] = beta;
+                    a.s.rho[i] = rho_new;
+                }
             }
             a.s.active[i] = act;
             if (act) atomicAdd(&cnt, 1);
@@ -629,34 +525,146 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_cocg_rho(fh_fin_args a) {
     if (t == 0) a.s.node_active[node] = cnt;
 }
 
-#define FH_DISPATCH_LD(ld, KERNEL, grid, st, args)                                         \
-    do {                                                                                    \
-        if ((ld) == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(FH_BLOCK), 0, st, args); \
-        else if ((ld) == 32) hipLaunchKernelGGL((KERNEL<32>), grid, dim3(FH_BLOCK), 0, st, args); \
-        else hipLaunchKernelGGL((KERNEL<64>), grid, dim3(FH_BLOCK), 0, st, args);           \
+// total number of active columns over all nodes -> *out (one block)
+__global__ void k_count_active(const int* node_active, int nodes, int* out) {
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < nodes; ++i) s += node_active[i];
+        *out = s;
+    }
+}
+
+// progress word for the host: the Krylov driver never blocks in hipStreamSynchronize while
+// iterating (each such round trip idles the GPU for milliseconds); it polls this word instead.
+__global__ void k_publish_progress(const int* node_active, int nodes, unsigned long long* progress, unsigned tag) {
+    if (threadIdx.x == 0) {
+        unsigned s = 0;
+        for (int i = 0; i < nodes; ++i) s += (unsigned)node_active[i];
+        // relaxed: the word itself is the whole message, no other data is handed to the host
+        __hip_atomic_store(progress, ((unsigned long long)tag << 32) | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// COCG (conjugate orthogonal CG) for COMPLEX SYMMETRIC shifted systems: real-symmetric (or
+// complex-symmetric) A, B with a complex shift give S = zB - A = S^T, so the BiCG recurrences
+// collapse to one operator application per iteration with the unconjugated bilinear form.
+// Per iteration: 1 SpMM (2 panel passes) + 6 + 3 vector passes, against 2 SpMM + 14 for BiCGStab.
+// ------------------------------------------------------------------------------------
+template <typename CT, int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_init(fh_vec_args a) {
+    // P = R ; partial1 = sum R*R (unconjugated), partial2 = sum |R|^2
+    const int node = blockIdx.y;
+    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+    const size_t total = (size_t)a.N * LD;
+    const CT* R = (const CT*)a.R + (size_t)node * a.node_stride;
+    CT* P = (CT*)a.P + (size_t)node * a.node_stride;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        CT r = R[e];
+        P[e] = r;
+        const cplx rd = to_d(r);
+        d1 = cadd(d1, cmul(rd, rd));
+        d2.x += cabs2(rd);
+    }
+    __shared__ cplx red[FH_BLOCK];
+    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+}
+
+template <typename CT, int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
+    // X += alpha P ; R -= alpha Q (Q stored in V) ; partial1 = sum R*R, partial2 = sum |R|^2
+    const int node = blockIdx.y;
+    const int c = threadIdx.x % LD;
+    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
+    if (on) {
+        const size_t total = (size_t)a.N * LD;
+        const CT alpha = cvt<CT>(a.s.alpha[node * LD + c]);
+        const CT* P = (const CT*)a.P + (size_t)node * a.node_stride;
+        const CT* Q = (const CT*)a.V + (size_t)node * a.node_stride;
+        CT* X = (CT*)a.X + (size_t)node * a.node_stride;
+        CT* R = (CT*)a.R + (size_t)node * a.node_stride;
+        for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+            CT x = X[e];
+            cfma(x, alpha, P[e]);
+            X[e] = x;
+            CT r = csub(R[e], cmul(alpha, Q[e]));
+            R[e] = r;
+            const cplx rd = to_d(r);
+            d1 = cadd(d1, cmul(rd, rd));
+            d2.x += cabs2(rd);
+        }
+    }
+    __shared__ cplx red[FH_BLOCK];
+    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+}
+
+template <typename CT, int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_p(fh_vec_args a) {
+    // P = R + beta P
+    const int node = blockIdx.y;
+    if (a.s.node_active[node] == 0) return;
+    const int c = threadIdx.x % LD;
+    if (!a.s.active[node * LD + c]) return;
+    const size_t total = (size_t)a.N * LD;
+    const CT beta = cvt<CT>(a.s.beta[node * LD + c]);
+    const CT* R = (const CT*)a.R + (size_t)node * a.node_stride;
+    CT* P = (CT*)a.P + (size_t)node * a.node_stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
+        P[e] = cadd(R[e], cmul(beta, P[e]));
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+#define FH_DISPATCH_VEC(prec, ld, KERNEL, grid, st, args)                                          \
+    do {                                                                                            \
+        if ((prec) == 32) {                                                                         \
+            if ((ld) == 16) hipLaunchKernelGGL((KERNEL<cplxf, 16>), grid, dim3(FH_BLOCK), 0, st, args); \
+            else if ((ld) == 32) hipLaunchKernelGGL((KERNEL<cplxf, 32>), grid, dim3(FH_BLOCK), 0, st, args); \
+            else hipLaunchKernelGGL((KERNEL<cplxf, 64>), grid, dim3(FH_BLOCK), 0, st, args);        \
+        } else {                                                                                    \
+            if ((ld) == 16) hipLaunchKernelGGL((KERNEL<cplx, 16>), grid, dim3(FH_BLOCK), 0, st, args); \
+            else if ((ld) == 32) hipLaunchKernelGGL((KERNEL<cplx, 32>), grid, dim3(FH_BLOCK), 0, st, args); \
+            else hipLaunchKernelGGL((KERNEL<cplx, 64>), grid, dim3(FH_BLOCK), 0, st, args);         \
+        }                                                                                           \
     } while (0)
 
-void fh_launch_init_guess(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_init_guess, dim3(nblk, nodes), st, a);
-}
-void fh_launch_copy_r(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_copy_r, dim3(nblk, nodes), st, a);
-}
-void fh_launch_p_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_p_update, dim3(nblk, nodes), st, a);
-}
-void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_s_update, dim3(nblk, nodes), st, a);
-}
-void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_xr_update, dim3(nblk, nodes), st, a);
-}
 #define FH_DISPATCH_FIN(ld, KERNEL, grid, st, args)                                           \
     do {                                                                                        \
         if ((ld) == 16) hipLaunchKernelGGL((KERNEL<16>), grid, dim3(FH_FIN_BLOCK), 0, st, args); \
         else if ((ld) == 32) hipLaunchKernelGGL((KERNEL<32>), grid, dim3(FH_FIN_BLOCK), 0, st, args); \
         else hipLaunchKernelGGL((KERNEL<64>), grid, dim3(FH_FIN_BLOCK), 0, st, args);           \
     } while (0)
+
+void fh_launch_init_guess(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(64, ld, k_init_guess, dim3(nblk, nodes), st, a);
+}
+void fh_launch_copy_r(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_copy_r, dim3(nblk, nodes), st, a);
+}
+void fh_launch_p_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_p_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_s_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_xr_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_cocg_init, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_cocg_update, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_cocg_p, dim3(nblk, nodes), st, a);
+}
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
     FH_DISPATCH_FIN(ld, k_fin_init, dim3(nodes), st, a);
 }
@@ -672,22 +680,20 @@ void fh_launch_fin_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st) 
 void fh_launch_count_active(const int* node_active, int nodes, int* out, hipStream_t st) {
     hipLaunchKernelGGL(k_count_active, dim3(1), dim3(64), 0, st, node_active, nodes, out);
 }
-
-void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_cocg_init, dim3(nblk, nodes), st, a);
+void fh_launch_publish_progress(const int* node_active, int nodes, unsigned long long* progress, unsigned tag, hipStream_t st) {
+    hipLaunchKernelGGL(k_publish_progress, dim3(1), dim3(64), 0, st, node_active, nodes, progress, tag);
 }
-void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_cocg_update, dim3(nblk, nodes), st, a);
+void fh_launch_narrow_scaled(const cplx* src, size_t src_stride, cplxf* dst, size_t dst_stride, const double* r0norm,
+                             int N, int ld, int nblk, int nodes, hipStream_t st) {
+    size_t total = (size_t)N * ld;
+    if (ld == 16) hipLaunchKernelGGL((k_narrow_scaled<16>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, src, src_stride, dst, dst_stride, r0norm, total);
+    else if (ld == 32) hipLaunchKernelGGL((k_narrow_scaled<32>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, src, src_stride, dst, dst_stride, r0norm, total);
+    else hipLaunchKernelGGL((k_narrow_scaled<64>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, src, src_stride, dst, dst_stride, r0norm, total);
 }
-void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
-    FH_DISPATCH_LD(ld, k_cocg_p, dim3(nblk, nodes), st, a);
-}
-void fh_launch_fin_cocg_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_FIN(ld, k_fin_cocg_init, dim3(nodes), st, a);
-}
-void fh_launch_fin_cocg_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_FIN(ld, k_fin_cocg_alpha, dim3(nodes), st, a);
-}
-void fh_launch_fin_cocg_rho(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
-    FH_DISPATCH_FIN(ld, k_fin_cocg_rho, dim3(nodes), st, a);
+void fh_launch_widen_axpy(cplx* X, size_t x_stride, const cplxf* D, size_t d_stride, const double* r0norm,
+                          int N, int ld, int nblk, int nodes, hipStream_t st) {
+    size_t total = (size_t)N * ld;
+    if (ld == 16) hipLaunchKernelGGL((k_widen_axpy<16>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, X, x_stride, D, d_stride, r0norm, total);
+    else if (ld == 32) hipLaunchKernelGGL((k_widen_axpy<32>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, X, x_stride, D, d_stride, r0norm, total);
+    else hipLaunchKernelGGL((k_widen_axpy<64>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, X, x_stride, D, d_stride, r0norm, total);
 }

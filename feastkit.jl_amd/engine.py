@@ -223,6 +223,16 @@ class HipEngine:
         self.last_stats = stats.asdict()
         return dY, rc
 
+    def last_node_iterations(self, n):
+        out = np.zeros(max(1, n), dtype=np.int32)
+        self._chk(self.lib.feasthip_last_node_iterations(self.h, _np_ptr(out), int(n)))
+        return out[:n]
+
+    def last_column_iterations(self, nodes, m):
+        out = np.zeros(max(1, nodes * m), dtype=np.int32)
+        self._chk(self.lib.feasthip_last_column_iterations(self.h, _np_ptr(out), int(nodes * m)))
+        return out[:nodes * m].reshape(nodes, m)
+
     # -- measurement ----------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self.lib.feasthip_profile_enable(self.h, int(on)))

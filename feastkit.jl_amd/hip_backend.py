@@ -75,7 +75,7 @@ def _reduced_hermitian_eig(Sq, Aq):
 def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
-                        preloaded=False, node_assignment="block"):
+                        preloaded=False, node_assignment="block", inner_precision=64):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -86,6 +86,10 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
       (lambda_j, q_j) seed the solves with Y0 = q_j/(z_e - lambda_j), whose residual is
       r_j/(z_e - lambda_j) -- Galerkin-orthogonal to the current subspace.  ``inner_rtol``
       then bounds the reduction relative to that initial residual (default solver_tol).
+    inner_precision: 64 | 32 (iterative solvers on sparse matrices).  32 solves the correction
+      (z_e B - A) d = r0/||r0|| of each warm-started system in complex64 and adds it back in
+      fp64; valid for inexact solves only (inner_rtol >= 1e-5).  Warm start, residuals,
+      orthonormalisation and Rayleigh-Ritz stay fp64, so the converged eigenpairs are unchanged.
     real_projection: None -> True for real-symmetric A, B.  Q_proj = Re(sum 2 w_e Y_e), the
       full-contour FEAST filter (what the reference's real paths do, feast_parallel.jl:38-55,
       feast_kernel.jl:183-186).  False keeps variant A's complex half-contour sum
@@ -126,10 +130,17 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         engine.set_node_range(first, count)
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
                       restart=solver_restart, cache_factors=True)
+    if inner_precision not in (32, 64):
+        raise ValueError("inner_precision must be 32 or 64")
     if iterative and warm_start:
         # inexact-solve mode: every loop reduces the (warm-started) residual by inner_rtol
         rt = tol_value if inner_rtol is None else float(inner_rtol)
-        engine.set_solver(solver, rtol=rt, atol=0.0, maxit=solver_maxiter, restart=solver_restart)
+        if inner_precision == 32 and rt < 1e-5:
+            raise ValueError("inner_precision=32 needs inner_rtol >= 1e-5 (single-precision correction solves)")
+        engine.set_solver(solver, rtol=rt, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
+                          factor_precision=inner_precision)
+    elif inner_precision == 32:
+        raise ValueError("inner_precision=32 requires the warm-started inexact iterative mode")
     t_setup = time.perf_counter() - t_setup
 
     Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
@@ -191,7 +202,9 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         V_sorted = np.asfortranarray(v_red[:, perm])
         if trace is not None:
             trace.append({"loop": loop_idx, "rank": rank_q, "M": M, "lambda": lam_sorted.copy(), "status": status.copy(),
-                          "stats": dict(st)})
+                          "stats": dict(st),
+                          "node_iterations": engine.last_node_iterations(count) if hasattr(engine, "last_node_iterations") else None,
+                          "column_iterations": engine.last_column_iterations(count, active) if hasattr(engine, "last_column_iterations") else None})
         if M == 0 and not (iterative and warm_start):
             info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
             break

@@ -206,6 +206,10 @@ int  feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double z_im, int
 /* Average device time (ms, HIP events on the handle's stream) and launch count of the
  * named kernel class since the last reset; classes: "spmm", "bicg_update", "dot_finalize",
  * "lu_panel", "lu_gemm", "trsm", "gram", "ortho".  Used by bench.py's roofline object.     */
+/* Per local node: iterations of the slowest column in the last iterative sweep. */
+int  feasthip_last_node_iterations(feasthip_handle h, int* out, int n);
+/* [local node][m] iterations per column of the last iterative sweep (row-major, n entries). */
+int  feasthip_last_column_iterations(feasthip_handle h, int* out, int n);
 int  feasthip_profile_enable(feasthip_handle h, int enable);
 int  feasthip_profile_reset(feasthip_handle h);
 int  feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms,

@@ -176,7 +176,9 @@ def test_cfg3_reduced_reference_mode_and_fast_mode(engine):
     assert fo.feast_hermitian(A, B, Emin, Emax, M0, ne=8).info == 5
     ref = fo.feast_hermitian(A, B, Emin, Emax, M0, ne=8, real_projection=True)
     assert ref.info == 0
-    for r in (strict, fast):
+    mixed = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm_with(f2=8, f4=40), engine=engine, solver="bicgstab",
+                     warm_start=True, inner_rtol=1e-2, solver_maxiter=100, inner_precision=32)
+    for r in (strict, fast, mixed):
         assert r.info == 0 and r.M == len(inside) == ref.M
         assert np.allclose(np.sort(r.lambda_), inside, atol=1e-10)
         assert np.allclose(np.sort(r.lambda_), np.sort(ref.lam), atol=1e-10)
@@ -194,7 +196,7 @@ def test_cfg3_full_size_properties(engine):
     inside = lam[(lam >= Emin) & (lam <= Emax)]
     assert len(inside) == 44
     r = fk.feast(A, B, (Emin, Emax), M0=64, fpm=fpm_with(f2=16, f4=40), engine=engine, solver="bicgstab",
-                 warm_start=True, inner_rtol=1e-2, solver_maxiter=100)
+                 warm_start=True, inner_rtol=1e-2, solver_maxiter=100, inner_precision=32)
     assert r.info == 0 and r.M == 44 and r.epsout <= 1e-12
     assert np.abs(np.sort(r.lambda_) - inside).max() <= 1e-10
     res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
