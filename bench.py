@@ -83,8 +83,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--inner-rtol", type=float, default=1e-2)
+    ap.add_argument("--inner-rtol", type=float, default=3e-2)
     ap.add_argument("--maxit", type=int, default=100)
+    ap.add_argument("--solver", default="cocg", choices=["cocg", "bicgstab"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -109,12 +110,12 @@ def main():
     eng = fk.HipEngine(local_rank)
     eng.set_problem(A, B)                     # one-time upload, outside the timed region
 
-    def step():
+    def step(precision=64):
         fpm = fk.feastinit()
         fpm[2], fpm[4] = 16, 40
-        return fk.feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver="bicgstab", warm_start=True,
+        return fk.feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=args.solver, warm_start=True,
                                       inner_rtol=args.inner_rtol, solver_maxiter=args.maxit, preloaded=True,
-                                      node_assignment="balanced")
+                                      node_assignment="balanced", inner_precision=precision)
 
     def fence():
         if world > 1:
@@ -131,6 +132,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     eng.profile_enable(False)
+    # secondary, untimed-for-`value` measurement: same solve with complex64 Krylov corrections
+    # (fp64 warm start / residual / Rayleigh-Ritz; identical converged eigenpairs)
+    step(32)
+    fence()
+    t1 = time.perf_counter()
+    mixed = step(32)
+    fence()
+    mixed_elapsed = time.perf_counter() - t1
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -155,12 +164,12 @@ def main():
     if launches > 0 and total_ms > 0:
         avg_ms = total_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_spmm<double,64,false>", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": "k_spmm<cplx,double,64,false>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
                     "alg_bytes_per_launch": int(alg_bytes / launches)}
     classes = {}
-    for cls in ("spmm", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz"):
+    for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz"):
         ms, n = eng.profile_get(cls)
         if n:
             classes[cls] = {"launches": int(n), "est_total_ms": round(ms, 2)}
@@ -171,12 +180,17 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg3: N=50000 sparse symmetric generalized (3-D Laplacian 50x40x25, B=I+0.1A), "
                                "interval (0,0.1775), 16 Gauss nodes, M0=64, tol 1e-12",
-                   "solver": "batched BiCGStab, warm-started from Ritz pairs, inner rtol %g, <=%d its/loop" % (args.inner_rtol, args.maxit),
+                   "solver": "batched %s, fp64, warm-started from Ritz pairs, inner rtol %g, <=%d its/loop"
+                             % ("COCG (BiCG for the complex-symmetric shifted systems)" if args.solver == "cocg" else "BiCGStab",
+                                args.inner_rtol, args.maxit),
                    "parallelism": "nodes/%d (near-axis nodes paired with far-axis nodes per GPU), 1 all-reduce of Q_proj per loop" % world},
         "eigenpairs": int(res.M), "expected_eigenpairs": int(len(inside)), "max_residual": max_res,
         "max_eigenvalue_error": eig_err, "loops": int(res.loop), "converged": bool(ok),
         "krylov_iterations_per_step": int(res.stats.get("krylov_iterations", 0)),
         "roofline": roofline, "kernel_classes": classes,
+        "mixed_precision": {"value": round(mixed.M / mixed_elapsed, 3) if mixed.info == 0 else 0.0, "unit": "eigenpairs/s",
+                            "note": "same solve with complex64 Krylov correction panels (not the headline value)",
+                            "max_residual_device": float(mixed.epsout), "loops": int(mixed.loop)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(A, B, len(inside))

@@ -42,9 +42,9 @@ void fh_free_bufs(feasthip_ctx* h) {
     h->bufs.clear();
 }
 
-// Sampled event timing: every FH_PROF_PERIOD-th launch of a class is bracketed by two events
+// Sampled event timing (1 launch in 8): every FH_PROF_PERIOD-th launch of a class is bracketed by two events
 // on the launch stream; the class average is (sum of sampled durations)/(samples).
-#define FH_PROF_PERIOD 4
+#define FH_PROF_PERIOD 8
 static thread_local int fh_prof_open = 0;
 void fh_prof_begin(feasthip_ctx* h, const char* cls) {
     fh_prof_open = 0;
@@ -856,6 +856,70 @@ extern "C" int feasthip_contour_apply(feasthip_handle h, int64_t m, const void* 
 }
 
 // ---------------------------------------------------------------------------------------
+// small host-side complex Hermitian helpers (m <= 64) for the Cholesky-QR fast path
+// ---------------------------------------------------------------------------------------
+// pivoted Cholesky pivots of a Hermitian PSD matrix (column-major, leading dim ld): returns
+// min/max pivot ratio.  In exact arithmetic these pivots are the squares of the diagonal of R
+// in the column-pivoted QR of the panel, so the ratio bounds the rank test of
+// _feast_qr_compress! (src/core/feast_aux.jl:117-124) from the safe side.
+static double fh_pivoted_cholesky_ratio(std::vector<cplx> G, int m, int ld) {
+    std::vector<int> perm(m);
+    for (int i = 0; i < m; ++i) perm[i] = i;
+    double dmax = 0.0, dmin = 0.0;
+    auto at = [&](int i, int j) -> cplx& { return G[(size_t)j * ld + i]; };
+    for (int k = 0; k < m; ++k) {
+        int p = k;
+        for (int j = k + 1; j < m; ++j) if (at(j, j).x > at(p, p).x) p = j;
+        if (p != k) {     // symmetric swap of rows/cols k and p
+            for (int j = 0; j < m; ++j) std::swap(at(k, j), at(p, j));
+            for (int i = 0; i < m; ++i) std::swap(at(i, k), at(i, p));
+        }
+        double d = at(k, k).x;
+        if (k == 0) dmax = d;
+        if (!(d > 0.0) || !std::isfinite(d)) return 0.0;
+        dmin = d;
+        double r = std::sqrt(d);
+        at(k, k) = cmake(r, 0);
+        for (int i = k + 1; i < m; ++i) at(i, k) = cscale(at(i, k), 1.0 / r);
+        for (int j = k + 1; j < m; ++j)
+            for (int i = j; i < m; ++i) {
+                cplx v = csub(at(i, j), cmul(at(i, k), cconj(at(j, k))));
+                at(i, j) = v;
+                at(j, i) = cconj(v);
+            }
+    }
+    return dmax > 0.0 ? dmin / dmax : 0.0;
+}
+
+// Rinv (ld x ld, column-major, zero padded) with G = R^H R, R upper triangular; false if not PD
+static bool fh_chol_upper_inverse(const std::vector<cplx>& G, int m, int ld, std::vector<cplx>& Rinv) {
+    std::vector<cplx> R((size_t)m * m, cmake(0, 0));
+    auto r = [&](int i, int j) -> cplx& { return R[(size_t)j * m + i]; };
+    for (int j = 0; j < m; ++j) {
+        for (int i = 0; i <= j; ++i) {
+            cplx sum = G[(size_t)j * ld + i];
+            for (int k = 0; k < i; ++k) sum = csub(sum, cmul(cconj(r(k, i)), r(k, j)));
+            if (i == j) {
+                if (!(sum.x > 0.0) || !std::isfinite(sum.x)) return false;
+                r(i, i) = cmake(std::sqrt(sum.x), 0);
+            } else {
+                r(i, j) = cscale(sum, 1.0 / r(i, i).x);
+            }
+        }
+    }
+    Rinv.assign((size_t)ld * ld, cmake(0, 0));
+    for (int j = 0; j < m; ++j) {          // back substitution, column by column
+        Rinv[(size_t)j * ld + j] = cmake(1.0 / r(j, j).x, 0);
+        for (int i = j - 1; i >= 0; --i) {
+            cplx sum = cmake(0, 0);
+            for (int k = i + 1; k <= j; ++k) sum = cadd(sum, cmul(r(i, k), Rinv[(size_t)j * ld + k]));
+            Rinv[(size_t)j * ld + i] = cscale(sum, -1.0 / r(i, i).x);
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------
 // orthonormalisation (a9)
 // ---------------------------------------------------------------------------------------
 extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void* dQ, double rank_tol, int* rank) {
@@ -879,6 +943,52 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
     if ((rc = fh_get_buf(h, "or_coef", FH_MAX_LD * sizeof(cplx), &p))) return rc;
     cplx* coef = (cplx*)p;
     fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
+    // Fast path (Cholesky-QR twice) when the panel is far from rank deficient: the pivoted
+    // Cholesky pivots of the Gram matrix are the squared R_kk of the pivoted QR, so a pivot
+    // ratio above 1e-10 means every |R_kk|/|R_11| > 1e-5 >> rank_tol and the reference rule
+    // keeps all m columns.  Otherwise fall through to the rank-revealing pivoted Gram-Schmidt.
+    if (!getenv("FH_NO_CHOLQR")) {
+        if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
+        cplx* gw = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gram_G", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+        cplx* G = (cplx*)p;
+        if ((rc = fh_get_buf(h, "or_Rinv", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+        cplx* dR = (cplx*)p;
+        std::vector<cplx> Gh((size_t)ld * ld), Rinv;
+        bool ok = true;
+        cplx* src = X;
+        cplx* dst = Out;
+        for (int pass = 0; pass < 2 && ok; ++pass) {
+            fh_prof_begin(h, "gram");
+            fh_launch_gram(src, src, N, ld, 0, gw, G, h->stream);
+            fh_prof_end(h);
+            FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+            FH_CHECK(hipStreamSynchronize(h->stream));
+            if (pass == 0) {
+                double ratio = fh_pivoted_cholesky_ratio(Gh, m, ld);
+                double thr = std::max(1e-10, rank_tol * rank_tol * 1e4);
+                if (!(ratio > thr)) { ok = false; break; }
+            }
+            if (!fh_chol_upper_inverse(Gh, m, ld, Rinv)) { ok = false; break; }
+            FH_CHECK(hipMemcpyAsync(dR, Rinv.data(), Rinv.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+            fh_prof_begin(h, "ortho");
+            fh_launch_small_matmul(src, dR, N, ld, dst, h->stream);
+            fh_prof_end(h);
+            FH_CHECK(hipStreamSynchronize(h->stream));     // Rinv (host vector) is reused
+            std::swap(src, dst);
+        }
+        if (ok) {
+            // two passes: the result is back in X (src after two swaps)
+            *rank = m;
+            fh_launch_from_panel(src, ld, N, m, (cplx*)dQ, N, h->stream);
+            FH_CHECK(hipStreamSynchronize(h->stream));
+            fh_prof_collect(h);
+            return 0;
+        }
+        // pass 0 failed before touching X; a failure in pass 1 leaves the first-pass result in
+        // `Out`, so re-read the input panel for the rank-revealing path
+        fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
+    }
     fh_mgs_args a;
     a.X = X; a.N = N; a.ld = ld; a.m = m; a.istate = istate; a.dstate = dstate; a.coef = coef; a.work = work;
     a.rank_tol = rank_tol;
