@@ -97,10 +97,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: FEAST_BENCH_BACKEND=gloo lets several ranks share device 0
+    backend = os.environ.get("FEAST_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -115,7 +121,7 @@ def main():
         fpm[2], fpm[4] = 16, 40
         return fk.feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=args.solver, warm_start=True,
                                       inner_rtol=args.inner_rtol, solver_maxiter=args.maxit, preloaded=True,
-                                      node_assignment="balanced", inner_precision=precision)
+                                      node_assignment="balanced", inner_precision=precision, column_groups="auto")
 
     def fence():
         if world > 1:
@@ -183,7 +189,7 @@ def main():
                    "solver": "batched %s, fp64, warm-started from Ritz pairs, inner rtol %g, <=%d its/loop"
                              % ("COCG (BiCG for the complex-symmetric shifted systems)" if args.solver == "cocg" else "BiCGStab",
                                 args.inner_rtol, args.maxit),
-                   "parallelism": "nodes/%d (near-axis nodes paired with far-axis nodes per GPU), 1 all-reduce of Q_proj per loop" % world},
+                   "parallelism": "%d ranks = (node groups) x (column groups of >=16 RHS columns), near/far-axis nodes paired, 1 all-reduce of Q_proj per loop" % world},
         "eigenpairs": int(res.M), "expected_eigenpairs": int(len(inside)), "max_residual": max_res,
         "max_eigenvalue_error": eig_err, "loops": int(res.loop), "converged": bool(ok),
         "krylov_iterations_per_step": int(res.stats.get("krylov_iterations", 0)),

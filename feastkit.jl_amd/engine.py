@@ -153,11 +153,17 @@ class HipEngine:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.torch.view_as_real(dX), op=dist.ReduceOp.SUM, group=group)
+            self.torch.cuda.current_stream(self.device).synchronize()   # result visible to the library's stream
         return dX
 
     def _sync_stream(self):
-        self._chk(self.lib.feasthip_set_stream(
-            self.h, C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
+        """Order the library behind torch.  torch's default stream has handle 0, for which
+        the library falls back to its own non-blocking stream, so pending torch work (slice
+        copies, the H2D/D2H halves of an all-reduce, NCCL kernels) is drained on the host
+        first; every C-ABI call returns synchronised, which orders torch behind the library."""
+        cur = self.torch.cuda.current_stream(self.device)
+        cur.synchronize()
+        self._chk(self.lib.feasthip_set_stream(self.h, C.c_void_p(cur.cuda_stream)))
 
     # -- hot path -------------------------------------------------------------------
     def contour_apply(self, dQ, m, ritz_lambda=None, want_moments=False):

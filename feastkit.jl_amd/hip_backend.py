@@ -75,7 +75,7 @@ def _reduced_hermitian_eig(Sq, Aq):
 def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
-                        preloaded=False, node_assignment="block", inner_precision=64):
+                        preloaded=False, node_assignment="block", inner_precision=64, column_groups=1):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -86,6 +86,14 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
       (lambda_j, q_j) seed the solves with Y0 = q_j/(z_e - lambda_j), whose residual is
       r_j/(z_e - lambda_j) -- Galerkin-orthogonal to the current subspace.  ``inner_rtol``
       then bounds the reduction relative to that initial residual (default solver_tol).
+    column_groups: g > 1 (iterative solvers, multi-rank) arranges the ranks as
+      (world/g node groups) x (g column groups): a rank sweeps its node group for only its
+      block of right-hand-side columns (blocks of >= 16 columns).  The reference shards nodes
+      only (feast_parallel.jl:433-447); with Krylov solves the near-axis nodes need 10x the
+      iterations of the others, so pure node sharding is bounded by the slowest node while
+      columns of one node cost the same.  "auto" picks the largest g dividing the world size
+      that leaves >= 16 columns per rank.  Q_proj columns are disjoint across column groups,
+      so the one all-reduce per loop is unchanged.
     inner_precision: 64 | 32 (iterative solvers on sparse matrices).  32 solves the correction
       (z_e B - A) d = r0/||r0|| of each warm-started system in complex64 and adds it back in
       fp64; valid for inexact solves only (inner_rtol >= 1e-5).  Warm start, residuals,
@@ -121,13 +129,34 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         real_projection = not (_isc(A) or _isc(B)) and (Q0 is None or not np.iscomplexobj(Q0) or
                                                         not np.any(np.imag(Q0)))
     engine.set_real_projection(bool(real_projection))
-    if node_assignment == "balanced" and world > 1:
-        nodes_here = balanced_contour_points(len(Zne), world)[rank]
+    if column_groups == "auto":
+        column_groups = 1
+        if iterative and world > 1:
+            for g in range(world, 0, -1):
+                if world % g == 0 and M0 // g >= 16:
+                    column_groups = g
+                    break
+    column_groups = int(column_groups)
+    if column_groups < 1 or world % column_groups != 0 or (column_groups > 1 and not iterative):
+        raise ValueError("column_groups must divide the world size and needs an iterative solver")
+    node_groups = world // column_groups
+    node_rank, col_rank = rank // column_groups, rank % column_groups
+    if node_assignment == "balanced" and node_groups > 1:
+        nodes_here = balanced_contour_points(len(Zne), node_groups)[node_rank]
         engine.set_node_list(nodes_here)
         count = len(nodes_here)
     else:
-        first, count = distribute_contour_points(len(Zne), world)[rank]
+        first, count = distribute_contour_points(len(Zne), node_groups)[node_rank]
         engine.set_node_range(first, count)
+
+    def column_block(ncols):
+        """[c0, c1) of this rank's column group: blocks in multiples of 16, remainder to the last."""
+        if column_groups == 1:
+            return 0, ncols
+        per = max(16, -(-ncols // column_groups // 16) * 16) if ncols >= 16 * column_groups else -(-ncols // column_groups)
+        c0 = min(ncols, col_rank * per)
+        c1 = ncols if col_rank == column_groups - 1 else min(ncols, c0 + per)
+        return c0, c1
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
                       restart=solver_restart, cache_factors=True)
     if inner_precision not in (32, 64):
@@ -161,7 +190,17 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
     for loop_idx in range(0, maxloop + 1):
         loop_count = loop_idx
         t_ = tick()
-        dP, status, st = engine.contour_apply(dQ, active, ritz_lambda if (iterative and warm_start) else None)
+        lam_guess = ritz_lambda if (iterative and warm_start) else None
+        if column_groups == 1:
+            dP, status, st = engine.contour_apply(dQ, active, lam_guess)
+        else:
+            c0, c1 = column_block(active)
+            dP = engine.empty(dQ.shape[0])
+            dP.zero_()
+            status, st = np.zeros(max(1, count), dtype=np.int32), {}
+            if c1 > c0:
+                dPs, status, st = engine.contour_apply(dQ[c0:c1], c1 - c0, None if lam_guess is None else lam_guess[c0:c1])
+                dP[c0:c1] = dPs[:c1 - c0]
         ph["apply"] += tick() - t_
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
         stats["spmm_calls"] += st.get("spmm_calls", 0)

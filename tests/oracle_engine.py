@@ -46,7 +46,7 @@ class OracleEngine:
         self.solver = solver
 
     def empty(self, m):
-        return torch.empty((m, self.N), dtype=torch.complex128)
+        return torch.zeros((m, self.N), dtype=torch.complex128)
 
     def upload(self, Q):
         return torch.from_numpy(np.ascontiguousarray(np.asarray(Q, dtype=np.complex128).T))

@@ -25,11 +25,11 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank,
 A, B, lam = fo.cfg3_problem(16, 12, 10)
 inside = lam[(lam >= 0) & (lam <= 0.42)]
 out = []
-for assign in ("block", "balanced"):
+for assign, cg in (("block", 1), ("balanced", 1), ("balanced", 2)):
     eng = fk.HipEngine(0)
     fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 40
-    r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, len(inside) + 12, fpm, solver="bicgstab", warm_start=True,
-                               inner_rtol=1e-2, solver_maxiter=100, node_assignment=assign)
+    r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 32, fpm, solver="bicgstab", warm_start=True,
+                               inner_rtol=1e-2, solver_maxiter=100, node_assignment=assign, column_groups=cg)
     out += [r.info, r.M, r.epsout] + list(np.sort(r.lambda_))
     eng.close()
 # dense LU path, general problem (full contour, 2 ranks x 8 nodes)
@@ -56,13 +56,13 @@ def test_two_ranks_one_gpu_match_single_rank(engine, tmp_path):
     A, B, lam = fo.cfg3_problem(16, 12, 10)
     inside = lam[(lam >= 0) & (lam <= 0.42)]
     fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 40
-    one = fk.feast_hip_hermitian(engine, A, B, 0.0, 0.42, len(inside) + 12, fpm, solver="bicgstab", warm_start=True,
+    one = fk.feast_hip_hermitian(engine, A, B, 0.0, 0.42, 32, fpm, solver="bicgstab", warm_start=True,
                                  inner_rtol=1e-2, solver_maxiter=100)
     n = len(inside)
-    for off in (0, 3 + n):
+    for off in (0, 3 + n, 2 * (3 + n)):
         assert (int(g0[off]), int(g0[off + 1])) == (0, n) == (one.info, one.M)
         assert g0[off + 2] <= 1e-12
         assert np.allclose(g0[off + 3: off + 3 + n], inside, atol=1e-10)
         assert np.allclose(g0[off + 3: off + 3 + n], np.sort(one.lambda_), atol=1e-10)
-    off = 2 * (3 + n)
+    off = 3 * (3 + n)
     assert (int(g0[off]), int(g0[off + 1])) == (0, 3) and np.allclose(g0[off + 2: off + 5], [0.5, 1.0, 2.0], atol=1e-8)

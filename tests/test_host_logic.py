@@ -184,6 +184,9 @@ eng2 = OracleEngine()
 rb = fk.feast_hip_hermitian(eng2, A, B, 0.0, 2.0, len(inside) + 10, fk.feastinit(), real_projection=True, node_assignment='balanced')
 assert eng2.node_list == fk.balanced_contour_points(8, 2)[dist.get_rank()]
 assert rb.M == r.M and np.allclose(np.sort(rb.lambda_), np.sort(r.lambda_), atol=1e-11)
+eng3 = OracleEngine()
+rc = fk.feast_hip_hermitian(eng3, A, B, 0.0, 2.0, 32, fk.feastinit(), real_projection=True, solver='bicgstab', warm_start=False, column_groups=2)
+assert eng3.count == 8 and rc.info == 0 and rc.M == r.M and np.allclose(np.sort(rc.lambda_), np.sort(r.lambda_), atol=1e-10)
 single = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 2.0, len(inside) + 10, fk.feastinit(), real_projection=True, group=dist.new_group([dist.get_rank()]) if False else None) if False else None
 g = fk.feast_hip_general(OracleEngine(), np.diag([0.5+0.1j, 1.0+0.2j, 2.0-0.1j, 4.0]), None, 1.0+0.1j, 1.3, 4, fk.feastinit())
 np.save(r"{out}/r%s.npy" % sys.argv[1], np.concatenate([[r.info, r.M, r.loop, r.epsout], np.sort(r.lambda_), [g.M], np.sort(g.lambda_.real)]))
