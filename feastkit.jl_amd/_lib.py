@@ -77,6 +77,13 @@ def load_library(path: str | None = None):
         raise FeastHipUnavailable(
             f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  feastkit.jl_amd has no CPU fallback.")
+    # PyTorch bundles its own HIP runtime (libamdhip64); load torch FIRST so that this library's
+    # dependency resolves to the runtime already in the process.  Loading ours first puts two
+    # HIP runtimes side by side and feasthip_create then fails (observed: code 7).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported
