@@ -267,15 +267,38 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, i
     for (int i = 0; i < NB; ++i) A[(size_t)c * N + k0 + i] = x[i];
 }
 
-// A22 -= L21 U12 : 64x64 tile per workgroup, 4x4 outputs per thread
+// A22 -= L21 U12 on v_mfma_f64_16x16x4_f64: 64x64 tile of A22 per workgroup, four waves as
+// 2x2 of 32x32, each wave 2x2 MFMA tiles.  The product is formed TRANSPOSED,
+//     D[c][i] = sum_k U[k][c] * L[i][k]      (A operand = U^T, B operand = L^T)
+// so that a lane's results (row = (l>>4)+4r -> c, col = l&15 -> i) are 16 consecutive rows of
+// one column of the column-major trailing matrix: 256 B contiguous per 16-lane group.
+// Complex product from four real MFMAs per tile: rr, ii, ri, ir;  Re = rr - ii, Im = ri + ir.
+typedef double lu_v4d __attribute__((ext_vector_type(4)));
+
 template <int NB>
 __global__ __launch_bounds__(FH_BLOCK) void k_lu_gemm(cplx* const* LUs, int N, int k0) {
     cplx* A = LUs[blockIdx.z];
     __shared__ cplx Ls[NB][64];
-    __shared__ cplx Us[NB][64 + 1];
+    __shared__ cplx Us[NB][64];
     const int t = threadIdx.x;
     const int base = k0 + NB;
     const int i0 = base + blockIdx.x * 64, c0 = base + blockIdx.y * 64;
+    const int lane = t & 63, wave = t >> 6;
+    const int wi = (wave & 1) * 32, wc = (wave >> 1) * 32;     // wave's 32x32 sub-tile
+    const int lr = lane & 15, lk = lane >> 4;
+    // issue the read of this lane's 16 trailing-matrix entries first: it overlaps the LDS fill
+    // and the MFMA loop instead of sitting exposed in front of the read-modify-write
+    cplx cv[2][2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + wc + 16 * a + lk + 4 * r;
+                const int i = i0 + wi + 16 * b + lr;
+                cv[a][b][r] = (i < N && c < N) ? A[(size_t)c * N + i] : cmake(0, 0);
+            }
     for (int e = t; e < NB * 64; e += FH_BLOCK) {
         int ii = e % 64, k = e / 64;
         Ls[k][ii] = (i0 + ii < N) ? A[(size_t)(k0 + k) * N + i0 + ii] : cmake(0, 0);
@@ -285,34 +308,43 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_gemm(cplx* const* LUs, int N, i
         Us[k][cc] = (c0 + cc < N) ? A[(size_t)(c0 + cc) * N + k0 + k] : cmake(0, 0);
     }
     __syncthreads();
-    const int ti = t % 16, tj = t / 16;
-    cplx acc[4][4];
+    lu_v4d rr[2][2], ii[2][2], ri[2][2], ir[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = cmake(0, 0);
-#pragma unroll 4
-    for (int k = 0; k < NB; ++k) {
-        cplx l[4], u[4];
+        for (int b = 0; b < 2; ++b) { rr[a][b] = (lu_v4d){0, 0, 0, 0}; ii[a][b] = rr[a][b]; ri[a][b] = rr[a][b]; ir[a][b] = rr[a][b]; }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) l[a] = Ls[k][ti + 16 * a];
+    for (int kk = 0; kk < NB; kk += 4) {
+        cplx u[2], l[2];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) u[b] = Us[k][tj + 16 * b];
+        for (int a = 0; a < 2; ++a) u[a] = Us[kk + lk][wc + 16 * a + lr];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 2; ++b) l[b] = Ls[kk + lk][wi + 16 * b + lr];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) cfma(acc[a][b], l[a], u[b]);
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                rr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].x, rr[a][b], 0, 0, 0);
+                ii[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].y, l[b].y, ii[a][b], 0, 0, 0);
+                ri[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].y, ri[a][b], 0, 0, 0);
+                ir[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].y, l[b].x, ir[a][b], 0, 0, 0);
+            }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int i = i0 + ti + 16 * a, c = c0 + tj + 16 * b;
-            if (i < N && c < N) {
-                cplx v = A[(size_t)c * N + i];
-                A[(size_t)c * N + i] = csub(v, acc[a][b]);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + wc + 16 * a + lk + 4 * r;
+                const int i = i0 + wi + 16 * b + lr;
+                if (i < N && c < N) {
+                    cplx v = cv[a][b][r];
+                    v.x -= rr[a][b][r] - ii[a][b][r];
+                    v.y -= ri[a][b][r] + ir[a][b][r];
+                    A[(size_t)c * N + i] = v;
+                }
             }
-        }
 }
 
 // ---- solve ------------------------------------------------------------------------------

@@ -241,3 +241,60 @@ def test_empty_and_edge_inputs(engine):
     # singular shift on the contour cannot happen for Hermitian input (Im z != 0); a 1x1 problem works
     r = fk.feast(np.array([[2.0]]), None, (1.0, 3.0), M0=1, engine=engine)
     assert r.info == 0 and r.M == 1 and abs(r.lambda_[0] - 2.0) < 1e-12
+
+
+def test_contour_variants_trapezoid_and_ellipse(engine):
+    """fpm[16]=1 (trapezoid) and fpm[18]=50 (flat ellipse) only change the host-side nodes and
+    weights (src/core/feast_tools.jl:212-284); the device sweep must follow."""
+    N = 300
+    A = fo.householder_conjugated_diag(0.02 * np.arange(N))
+    want = 0.02 * np.arange(100, 108)
+    for kw in (dict(f16=1, f2=12), dict(f18=50, f2=8), dict(f16=1, f18=30, f2=16)):
+        r = fk.feast(A, None, (1.99, 2.15), M0=20, fpm=fpm_with(**kw), engine=engine)
+        assert r.info == 0 and r.M == 8 and np.allclose(np.sort(r.lambda_), want, atol=1e-10), kw
+        o = fo.feast_hermitian(A, None, 1.99, 2.15, 20, ne=kw["f2"], fpm16=kw.get("f16", 0), fpm18=kw.get("f18", 100),
+                               real_projection=True)
+        assert o.info == 0 and np.allclose(np.sort(o.lam), want, atol=1e-10)
+
+
+def test_complex_hermitian_sparse_generalized_bicgstab(engine):
+    """Complex Hermitian A, B (no real projection, half contour): BiCGStab path, parity with the
+    oracle's direct variant A and with dense eigh."""
+    N = 400
+    rng = np.random.default_rng(7)
+    S = sp.random(N, N, density=4.0 / N, random_state=3, format="csr")
+    S = S + 1j * sp.random(N, N, density=4.0 / N, random_state=4, format="csr")
+    A = sp.csr_matrix(S + S.conj().T + sp.diags(np.linspace(1.0, 40.0, N)))
+    T = sp.random(N, N, density=2.0 / N, random_state=5, format="csr") * (0.3 + 0.2j)
+    B = sp.csr_matrix(T + T.conj().T + sp.diags(2.0 + rng.random(N)))
+    import scipy.linalg as sla
+    ev = sla.eigh(A.toarray(), B.toarray(), eigvals_only=True)
+    lo, hi = ev[5] - 1e-3, ev[14] + 1e-3
+    inside = ev[(ev >= lo) & (ev <= hi)]
+    r = fk.feast(A, B, (lo, hi), M0=len(inside) + 14, fpm=fpm_with(f2=8, f4=80), engine=engine, solver="bicgstab",
+                 solver_tol=1e-13, solver_maxiter=3000)
+    o = fo.feast_hermitian(A, B, lo, hi, len(inside) + 14, ne=8, fpm4=80)
+    assert r.M == len(inside) == o.M and r.info == o.info == 0
+    assert np.allclose(np.sort(r.lambda_), inside, atol=1e-9) and np.allclose(np.sort(o.lam), inside, atol=1e-9)
+    res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert res.max() <= 1e-10
+    with pytest.raises(fk.FeastHipError):       # COCG is only for complex-symmetric shifted systems
+        fk.feast(A, B, (lo, hi), M0=len(inside) + 14, engine=engine, solver="cocg", warm_start=True, inner_rtol=1e-2)
+
+
+def test_dense_generalized_real_symmetric_cfg2_variant(engine):
+    """cfg 2 variant with B = H diag(1 + 0.5 u) H, N = 512."""
+    N = 512
+    rng = np.random.default_rng(20260515)
+    A = fo.householder_conjugated_diag(0.01 * np.arange(N))
+    v = rng.standard_normal(N); v /= np.linalg.norm(v)
+    H = np.eye(N) - 2 * np.outer(v, v)
+    B = H @ np.diag(1 + 0.5 * rng.random(N)) @ H
+    B = 0.5 * (B + B.T)
+    import scipy.linalg as sla
+    ev = sla.eigh(A, B, eigvals_only=True)
+    lo, hi = 0.5 * (ev[99] + ev[100]), 0.5 * (ev[118] + ev[119])     # edges in the middle of spectral gaps
+    inside = ev[(ev >= lo) & (ev <= hi)]
+    r = fk.feast(A, B, (lo, hi), M0=32, fpm=fpm_with(f2=8), engine=engine)
+    assert r.info == 0 and r.M == len(inside) and np.allclose(np.sort(r.lambda_), inside, atol=1e-10)
+    assert r.epsout <= 1e-12
