@@ -146,19 +146,42 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
         const CT ca = cvt<CT>(a.coefA[node * LD + c]);
         const CT cb = cvt<CT>(a.coefB[node * LD + c]);
         cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
-        for (int i = row_lo + slot * 16 + wave * 4 + g; i < row_hi; i += band) {
-            const int k0 = rowptr[i], k1 = rowptr[i + 1];
+        // software pipeline over this group's rows: row pointers are fetched two rows ahead and
+        // the first 16 nonzeros' (column, A, B) one row ahead, so a row's critical path is the
+        // X gather alone instead of rowptr -> (col, val) -> gather in series
+        const int i_first = row_lo + slot * 16 + wave * 4 + g;
+        int k0n = 0, k1n = 0, k0nn = 0, k1nn = 0;
+        if (i_first < row_hi) { k0n = rowptr[i_first]; k1n = rowptr[i_first + 1]; }
+        if (i_first + band < row_hi) { k0nn = rowptr[i_first + band]; k1nn = rowptr[i_first + band + 1]; }
+        int ncol = 0; VT na = fh_vzero(VT()), nb = fh_vzero(VT());
+        if (i_first < row_hi && k0n + l16 < k1n) {
+            ncol = colidx[k0n + l16]; na = aval[k0n + l16];
+            if (!BIDENT) nb = bval[k0n + l16];
+        }
+        for (int i = i_first; i < row_hi; i += band) {
+            const int k0 = k0n, k1 = k1n;
+            int mycol = ncol; VT mya = na, myb = nb;
+            // prefetch for the next row of this group
+            k0n = k0nn; k1n = k1nn;
+            if (i + 2 * band < row_hi) { k0nn = rowptr[i + 2 * band]; k1nn = rowptr[i + 2 * band + 1]; }
+            ncol = 0; na = fh_vzero(VT()); nb = fh_vzero(VT());
+            if (i + band < row_hi && k0n + l16 < k1n) {
+                ncol = colidx[k0n + l16]; na = aval[k0n + l16];
+                if (!BIDENT) nb = bval[k0n + l16];
+            }
             CT acc = fh_czero<CT>();
             CT xown = fh_czero<CT>();
             if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4) xown = X[(size_t)i * LD + c];
             if (BIDENT) acc = cmul(cb, xown);            // B = I contributes cb * x_i
             for (int kb = k0; kb < k1; kb += 16) {
-                const int kk = kb + l16;
-                const bool in = kk < k1;
-                const int mycol = in ? colidx[kk] : 0;
-                const VT mya = in ? aval[kk] : fh_vzero(VT());
-                VT myb = fh_vzero(VT());
-                if (!BIDENT) myb = in ? bval[kk] : fh_vzero(VT());
+                if (kb != k0) {                          // rows longer than 16 nonzeros: load on demand
+                    const int kk = kb + l16;
+                    const bool in = kk < k1;
+                    mycol = in ? colidx[kk] : 0;
+                    mya = in ? aval[kk] : fh_vzero(VT());
+                    myb = fh_vzero(VT());
+                    if (!BIDENT) myb = in ? bval[kk] : fh_vzero(VT());
+                }
                 CT mys = fh_czero<CT>();
                 if (a.uniform_coef) {                     // same (ca, cb) in every lane of the row
                     mys = vmul(mya, ca);
