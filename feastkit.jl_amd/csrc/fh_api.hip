@@ -672,6 +672,166 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// restarted GMRES(m) on panels -- the reference's iterative solver
+// (solve_shifted_iterative!, src/sparse/feast_sparse.jl:164-203; Krylov.jl gmres with
+// restart=true, memory=m, zero initial guess unless X holds one, stop ||r|| <= atol + rtol ||r0||).
+// All columns of a node advance in lock-step through modified Gram-Schmidt Arnoldi; the panel
+// operations run on the device (operator, per-column dots, axpys), the (m+1) x m Hessenberg
+// least-squares problems per column are kept on the host.  Provided for API completeness
+// (`solver = :gmres`): it is host-synchronous and not performance-tuned -- the batched
+// BiCG-family solvers above are the fast path.
+// ---------------------------------------------------------------------------------------
+static int fh_gmres(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, cplx* X,
+                    size_t stride, fh_solve_result& res) {
+    const int N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    const int mr = std::max(h->restart, 2);
+    int rc;
+    void* p;
+    if ((rc = fh_get_buf(h, "gm_V", (size_t)(mr + 2) * panel * sizeof(cplx), &p))) return rc;
+    cplx* V = (cplx*)p;                       // V_0 .. V_mr, then W
+    cplx* W = V + (size_t)(mr + 1) * panel;
+    const int nblk_vec = fh_vec_nblk(N, ld);
+    if ((rc = fh_get_buf(h, "gm_part", (size_t)std::max(nblk_vec, fh_op_nblk(h, ld)) * ld * sizeof(cplx), &p))) return rc;
+    cplx* part = (cplx*)p;
+    if ((rc = fh_get_buf(h, "gm_dots", (size_t)ld * sizeof(cplx), &p))) return rc;
+    cplx* ddots = (cplx*)p;
+    std::vector<cplx> dots(ld), coef(ld);
+    res.status.assign(nodes, 0);
+    auto dot_cols = [&](const cplx* U, const cplx* Vv) -> int {
+        fh_launch_dot_cols(U, Vv, N, ld, part, ddots, h->stream);
+        if (hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 7;
+        return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 7;
+    };
+    for (int e = 0; e < nodes; ++e) {
+        cplx* Xe = X + (size_t)e * stride;
+        std::vector<cplx> ca(ld, cmake(-1, 0)), cb(ld, z[e]);
+        cplx *dca, *dcb;
+        if ((rc = fh_upload_coefs(h, "gm_coefA", ca, &dca))) return rc;
+        if ((rc = fh_upload_coefs(h, "gm_coefB", cb, &dcb))) return rc;
+        fh_op_call oc;
+        oc.m = m; oc.uniform_coef = 1; oc.coefA = dca; oc.coefB = dcb; oc.nodes = 1;
+        oc.partial1 = nullptr; oc.partial2 = nullptr; oc.U = nullptr; oc.u_stride = 0; oc.node_active = nullptr;
+        oc.x_stride = 0; oc.y_stride = 0; oc.b_stride = 0; oc.dot_mode = 0;
+        std::vector<double> target(m, 0.0), r0n(m, 0.0), rn(m, 0.0);
+        std::vector<int> its(m, 0);
+        std::vector<char> done(m, 0);
+        bool first = true;
+        int total_it = 0;
+        while (total_it < h->maxit) {
+            // r = b - S x ; beta = ||r||
+            oc.X = Xe; oc.Y = V; oc.Bvec = RHS;
+            fh_apply_operator(h, ld, oc);
+            res.op_calls += 1;
+            if (dot_cols(V, V)) return FEASTHIP_ERROR_INTERNAL;
+            std::vector<double> beta(m);
+            bool any = false;
+            for (int c = 0; c < m; ++c) {
+                beta[c] = std::sqrt(dots[c].x);
+                rn[c] = beta[c];
+                if (first) { r0n[c] = beta[c]; target[c] = h->atol + h->rtol * beta[c]; }
+                if (!(beta[c] > target[c]) || !std::isfinite(beta[c])) done[c] = 1;
+                if (!done[c]) any = true;
+            }
+            first = false;
+            if (!any) break;
+            for (int c = 0; c < ld; ++c) coef[c] = (c < m && !done[c] && beta[c] > 0) ? cmake(1.0 / beta[c], 0) : cmake(0, 0);
+            cplx* dco;
+            if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
+            fh_launch_scale_cols(V, dco, N, ld, h->stream);               // v_0 = r / beta (0 for finished columns)
+            // per-column Hessenberg data
+            std::vector<std::vector<cplx>> H(m, std::vector<cplx>((size_t)(mr + 1) * mr, cmake(0, 0)));
+            std::vector<std::vector<cplx>> cs(m, std::vector<cplx>(mr)), sn(m, std::vector<cplx>(mr)), g(m, std::vector<cplx>(mr + 1, cmake(0, 0)));
+            std::vector<int> kc(m, 0);             // Krylov dimension used by each column in this cycle
+            for (int c = 0; c < m; ++c) g[c][0] = cmake(beta[c], 0);
+            int k = 0;
+            for (; k < mr && total_it < h->maxit; ++k) {
+                cplx* Vk = V + (size_t)k * panel;
+                oc.X = Vk; oc.Y = W; oc.Bvec = nullptr;
+                fh_apply_operator(h, ld, oc);                               // w = S v_k
+                res.op_calls += 1;
+                for (int i = 0; i <= k; ++i) {                                // modified Gram-Schmidt
+                    cplx* Vi = V + (size_t)i * panel;
+                    if (dot_cols(Vi, W)) return FEASTHIP_ERROR_INTERNAL;
+                    for (int c = 0; c < ld; ++c) coef[c] = (c < m && !done[c]) ? dots[c] : cmake(0, 0);
+                    for (int c = 0; c < m; ++c) if (!done[c]) H[c][(size_t)k * (mr + 1) + i] = dots[c];
+                    if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
+                    fh_launch_axpy_cols(W, Vi, dco, N, ld, h->stream);     // w -= h_ik v_i
+                }
+                if (dot_cols(W, W)) return FEASTHIP_ERROR_INTERNAL;
+                bool any_active = false;
+                for (int c = 0; c < ld; ++c) coef[c] = cmake(0, 0);
+                for (int c = 0; c < m; ++c) {
+                    if (done[c]) continue;
+                    double hk1 = std::sqrt(dots[c].x);
+                    cplx* Hc = &H[c][(size_t)k * (mr + 1)];
+                    Hc[k + 1] = cmake(hk1, 0);
+                    for (int i = 0; i < k; ++i) {                            // previous rotations
+                        cplx t = cadd(cmul(cs[c][i], Hc[i]), cmul(sn[c][i], Hc[i + 1]));
+                        Hc[i + 1] = cadd(cmul(cmake(-sn[c][i].x, sn[c][i].y), Hc[i]), cmul(cs[c][i], Hc[i + 1]));
+                        Hc[i] = t;
+                    }
+                    cplx a = Hc[k], b = Hc[k + 1];
+                    double aa = std::sqrt(cabs2(a)), den = std::sqrt(cabs2(a) + cabs2(b));
+                    if (den == 0.0) { cs[c][k] = cmake(1, 0); sn[c][k] = cmake(0, 0); }
+                    else if (aa == 0.0) { cs[c][k] = cmake(0, 0); sn[c][k] = cmake(1, 0); }
+                    else {
+                        cs[c][k] = cmake(aa / den, 0);
+                        sn[c][k] = cscale(cmul(cscale(a, 1.0 / aa), cconj(b)), 1.0 / den);
+                    }
+                    Hc[k] = cadd(cmul(cs[c][k], a), cmul(sn[c][k], b));
+                    Hc[k + 1] = cmake(0, 0);
+                    g[c][k + 1] = cmul(cmake(-sn[c][k].x, sn[c][k].y), g[c][k]);
+                    g[c][k] = cmul(cs[c][k], g[c][k]);
+                    its[c] += 1;
+                    kc[c] = k + 1;
+                    rn[c] = std::sqrt(cabs2(g[c][k + 1]));
+                    if (!(rn[c] > target[c]) || hk1 == 0.0) done[c] = 1;     // converged (or lucky breakdown)
+                    else { any_active = true; coef[c] = cmake(1.0 / hk1, 0); }
+                }
+                total_it += 1;
+                if (!any_active) { ++k; break; }
+                if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
+                fh_launch_scale_cols(W, dco, N, ld, h->stream);              // v_{k+1} = w / h_{k+1,k}
+                FH_CHECK(hipMemcpyAsync(V + (size_t)(k + 1) * panel, W, panel * sizeof(cplx), hipMemcpyDeviceToDevice, h->stream));
+            }
+            // x += V y, y from the triangular systems
+            std::vector<std::vector<cplx>> y(m);
+            int kmax = 0;
+            for (int c = 0; c < m; ++c) {
+                int kk = kc[c];
+                kmax = std::max(kmax, kk);
+                y[c].assign(kk, cmake(0, 0));
+                for (int i = kk - 1; i >= 0; --i) {
+                    cplx sacc = g[c][i];
+                    for (int j = i + 1; j < kk; ++j) sacc = csub(sacc, cmul(H[c][(size_t)j * (mr + 1) + i], y[c][j]));
+                    cplx d = H[c][(size_t)i * (mr + 1) + i];
+                    y[c][i] = cabs2(d) > 0 ? cdiv(sacc, d) : cmake(0, 0);
+                }
+            }
+            for (int i = 0; i < kmax; ++i) {
+                for (int c = 0; c < ld; ++c) coef[c] = (c < m && i < (int)y[c].size()) ? cmake(-y[c][i].x, -y[c][i].y) : cmake(0, 0);
+                if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
+                fh_launch_axpy_cols(Xe, V + (size_t)i * panel, dco, N, ld, h->stream);   // x -= (-y_i) v_i
+            }
+            // columns flagged done inside the cycle are re-examined with the true residual next cycle
+            for (int c = 0; c < m; ++c) done[c] = 0;
+        }
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        int mx = 0, st = 0;
+        for (int c = 0; c < m; ++c) {
+            mx = std::max(mx, its[c]);
+            res.col_iters.push_back(its[c]);
+            if (rn[c] > target[c]) st = FEASTHIP_ERROR_NO_CONVERGENCE;
+            if (r0n[c] > 0) res.max_rel_res = std::max(res.max_rel_res, rn[c] / r0n[c]);
+        }
+        res.iters_sum += mx; res.node_iters.push_back(mx); res.max_iters = std::max(res.max_iters, mx);
+        res.status[e] = st;
+    }
+    return 0;
+}
+
 static bool fh_is_complex_input(feasthip_ctx* h) { return h->kind == 2 ? h->csr.is_complex != 0 : h->dense.is_complex != 0; }
 
 // ---------------------------------------------------------------------------------------
@@ -769,8 +929,33 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
             stats->max_rel_residual = sr.max_rel_res;
         }
     } else {
-        h->last_error = "solver GMRES is not implemented on the device yet; use BICGSTAB";
-        return FEASTHIP_ERROR_FPM;
+        // GMRES: zero initial guess like Krylov.jl (or the Ritz warm start when given)
+        cplx* dz;
+        if ((rc = fh_upload_coefs(h, "ca_z", z, &dz))) return rc;
+        double* dlam = nullptr;
+        if (ritz_lambda) {
+            std::vector<double> lam(ld, 0.0);
+            for (int c = 0; c < m; ++c) lam[c] = ritz_lambda[c];
+            if ((rc = fh_get_buf(h, "ca_lam", ld * sizeof(double), &p))) return rc;
+            dlam = (double*)p;
+            FH_CHECK(hipMemcpy(dlam, lam.data(), ld * sizeof(double), hipMemcpyHostToDevice));
+        }
+        fh_vec_args va;
+        memset(&va, 0, sizeof(va));
+        va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz; va.prec = 64;
+        fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
+        fh_solve_result sr;
+        rc = fh_gmres(h, ld, m, nodes, z, Rhs, Y, panel, sr);
+        if (rc) return rc;
+        status = sr.status;
+        h->last_node_iters = sr.node_iters;
+        h->last_col_iters = sr.col_iters;
+        h->last_col_m = m;
+        if (stats) {
+            stats->krylov_iterations = sr.iters_sum;
+            stats->spmm_calls = sr.op_calls;
+            stats->max_rel_residual = sr.max_rel_res;
+        }
     }
     FH_CHECK(hipEventRecord(ev1, h->stream));
 
@@ -1286,8 +1471,12 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         status = sr.status;
         if (stats) { stats->krylov_iterations = sr.iters_sum; stats->spmm_calls = sr.op_calls; stats->max_rel_residual = sr.max_rel_res; }
     } else {
-        h->last_error = "solver GMRES is not implemented on the device yet; use BICGSTAB";
-        return FEASTHIP_ERROR_FPM;
+        FH_CHECK(hipMemsetAsync(Y, 0, panel * sizeof(cplx), h->stream));
+        fh_solve_result sr;
+        rc = fh_gmres(h, ld, m, 1, z, Rhs, Y, panel, sr);
+        if (rc) return rc;
+        status = sr.status;
+        if (stats) { stats->krylov_iterations = sr.iters_sum; stats->spmm_calls = sr.op_calls; stats->max_rel_residual = sr.max_rel_res; }
     }
     fh_launch_from_panel(Y, ld, N, m, (cplx*)dY, N, h->stream);
     FH_CHECK(hipStreamSynchronize(h->stream));

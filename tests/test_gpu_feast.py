@@ -98,6 +98,20 @@ def test_iterative_equals_direct_tridiag12(engine):
     assert np.allclose(np.sort(g.lambda_), np.sort(d.lambda_), atol=k["atol"])
 
 
+def test_gmres_keyword_equals_direct_tridiag12(engine):
+    """solver=:gmres with the reference's keywords (solver_tol, maxiter, restart), runtests.jl:552-580."""
+    k = K["gmres_equiv_tridiag12"]
+    A = sparse_tridiag(12)
+    d = fk.feast(A.toarray(), None, tuple(k["interval"]), M0=12, engine=engine)
+    g = fk.feast(A, None, tuple(k["interval"]), M0=12, engine=engine, solver="gmres", solver_tol=k["solver_tol"],
+                 solver_maxiter=k["maxiter"], solver_restart=k["restart"])
+    assert d.info == 0 and g.info == 0 and d.M == g.M == len(k["expect_lambda"])
+    assert np.allclose(np.sort(g.lambda_), np.sort(d.lambda_), atol=k["atol"])
+    gd = fk.feast(A.toarray(), None, tuple(k["interval"]), M0=12, engine=engine, solver="gmres", solver_tol=1e-8,
+                  solver_maxiter=400, solver_restart=20, fpm=fpm_with(f3=8))
+    assert gd.info == 0 and np.allclose(np.sort(gd.lambda_), np.sort(d.lambda_), atol=1e-8)
+
+
 def test_mpi_complex_fixtures(engine):
     k = K["mpi_complex_hermitian_diag4"]
     A = sp.diags(np.array(k["diag"], dtype=complex)).tocsr()

@@ -247,3 +247,27 @@ def test_mixed_precision_correction_solve(engine, solver, N, m):
     rel = np.linalg.norm(S @ Y - X, axis=0) / np.linalg.norm(X, axis=0)
     assert rel.max() < 3e-4
     engine.set_solver("direct")
+
+
+@pytest.mark.parametrize("N,m,restart", [(200, 7, 30), (1000, 32, 20), (1500, 64, 40)])
+@pytest.mark.parametrize("dense", [False, True])
+def test_gmres_shifted_solve(engine, N, m, restart, dense):
+    """Restarted GMRES(m) with the reference's stop test ||r|| <= atol + rtol ||r0||."""
+    A, B = sparse_pair(N, 5)
+    if dense:
+        A, B = A.toarray(), B.toarray()
+    engine.set_problem(A, B)
+    engine.set_solver("gmres", rtol=1e-10, atol=1e-10, maxit=600, restart=restart)
+    z = -3.0 + 2.0j
+    X = rand_block(N, m, 8)
+    dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    assert rc == 0
+    Y = engine.download(dY)
+    S = z * B - A
+    rel = np.linalg.norm(S @ Y - X, axis=0) / np.linalg.norm(X, axis=0)
+    assert rel.max() < 1e-9
+    # same answer as the oracle's per-column restarted GMRES
+    mv = lambda x: S @ x
+    xo, ok, _ = fo.gmres_restarted(mv, X[:, 0], 1e-10, 1e-10, 600, restart)
+    assert ok and np.abs(xo - Y[:, 0]).max() <= 1e-7 * np.abs(xo).max()
+    engine.set_solver("direct")
