@@ -126,8 +126,9 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
     if real_projection is None:
         import scipy.sparse as _sp
         _isc = lambda M_: M_ is not None and np.iscomplexobj(M_.data if _sp.issparse(M_) else M_)
-        real_projection = not (_isc(A) or _isc(B)) and (Q0 is None or not np.iscomplexobj(Q0) or
-                                                        not np.any(np.imag(Q0)))
+        q_real = Q0 is None or (hasattr(Q0, "data_ptr") and not bool((Q0.imag != 0).any())) or \
+            (not hasattr(Q0, "data_ptr") and (not np.iscomplexobj(Q0) or not np.any(np.imag(Q0))))
+        real_projection = not (_isc(A) or _isc(B)) and q_real
     engine.set_real_projection(bool(real_projection))
     if column_groups == "auto":
         column_groups = 1
@@ -172,8 +173,11 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         raise ValueError("inner_precision=32 requires the warm-started inexact iterative mode")
     t_setup = time.perf_counter() - t_setup
 
-    Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
-    dQ = engine.upload(Q_host)
+    if Q0 is not None and hasattr(Q0, "data_ptr"):
+        dQ = Q0.clone()                           # initial subspace already resident on the device (M0 x N)
+    else:
+        Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
+        dQ = engine.upload(Q_host)
     maxloop = int(fpm[4])
     eps_tol = feast_tolerance(fpm)
     epsout, info, loop_count, M_found, active = math.inf, 0, 0, 0, M0
