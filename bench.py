@@ -161,21 +161,46 @@ def main():
     max_res = float(host_res.max()) if res.M else float("nan")
     value = (sum(r.M for r in results) / elapsed) if ok else 0.0
 
-    # ---- roofline of the dominant kernel (SpMM Y = (zB - A) X over the node batch) -------------
+    # ---- roofline of the dominant kernel ---------------------------------------------------------
+    # candidates: the SpMM Y = (zB - A) X and the Krylov update kernel (x += a p, r -= a q, fused dots);
+    # the one with the larger share of the timed region is reported, the other kept under
+    # "roofline_other".  Algorithmic bytes come from device-side counters of active (node, column)
+    # work per launch; the average launch time from HIP events on the launch stream (1 launch in 8).
     N, nnz = A.shape[0], A.nnz
-    total_ms, launches = eng.profile_get("spmm")
-    _, node_launches = eng.profile_get("spmm.node_launches")
-    _, col_passes = eng.profile_get("spmm.column_passes")
-    matrix_bytes = nnz * (4 + 8 + 8) + 4 * (N + 1)            # col idx + A,B values (f64) + row pointers
-    alg_bytes = node_launches * matrix_bytes + col_passes * N * 16
-    roofline = None
-    if launches > 0 and total_ms > 0:
+    upd_cls = "cocg_xr" if args.solver == "cocg" else "bicg_xr"
+    upd_passes = 6 if args.solver == "cocg" else 7
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
+    except Exception:
+        pass
+
+    def roof(cls, kernel, alg_bytes):
+        total_ms, launches = eng.profile_get(cls)
+        if not (launches > 0 and total_ms > 0):
+            return None
         avg_ms = total_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_spmm<cplx,double,64,false>", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launches": int(launches), "avg_launch_ms": round(avg_ms, 4),
-                    "alg_bytes_per_launch": int(alg_bytes / launches)}
+        traffic = None
+        for name, rec in pmc.items():          # HBM bytes per launch from the committed PMC passes of this command
+            if name.replace(" ", "").startswith("void" + kernel.split("<")[0]) and ("cplx," in name or "<cplx" in name) and "cplxf" not in name:
+                traffic = rec["mean_hbm_bytes_per_launch"]
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same command)" if traffic else None,
+                "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes / launches),
+                "share_of_step": round(total_ms / (1e3 * elapsed), 3)}
+
+    _, node_launches = eng.profile_get("spmm.node_launches")
+    _, col_passes = eng.profile_get("spmm.column_passes")
+    _, upd_cols = eng.profile_get("update.active_columns")
+    matrix_bytes = nnz * (4 + 8 + 8) + 4 * (N + 1)            # col idx + A,B values (f64) + row pointers
+    r_spmm = roof("spmm", "k_spmm<cplx,double,64,false>", node_launches * matrix_bytes + col_passes * N * 16)
+    r_upd = roof(upd_cls, "k_cocg_update<cplx,64>" if args.solver == "cocg" else "k_xr_update<cplx,64>", upd_cols * upd_passes * N * 16)
+    cands = [r for r in (r_spmm, r_upd) if r]
+    cands.sort(key=lambda r: -r["share_of_step"])
+    roofline = cands[0] if cands else None
+    roofline_other = cands[1] if len(cands) > 1 else None
     classes = {}
     for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz"):
         ms, n = eng.profile_get(cls)
@@ -195,7 +220,7 @@ def main():
         "eigenpairs": int(res.M), "expected_eigenpairs": int(len(inside)), "max_residual": max_res,
         "max_eigenvalue_error": eig_err, "loops": int(res.loop), "converged": bool(ok),
         "krylov_iterations_per_step": int(res.stats.get("krylov_iterations", 0)),
-        "roofline": roofline, "kernel_classes": classes,
+        "roofline": roofline, "roofline_other": roofline_other, "kernel_classes": classes,
         "mixed_precision": {"value": round(mixed.M / mixed_elapsed, 3) if mixed.info == 0 else 0.0, "unit": "eigenpairs/s",
                             "note": "same solve with complex64 Krylov correction panels (not the headline value)",
                             "max_residual_device": float(mixed.epsout), "loops": int(mixed.loop)},

@@ -522,6 +522,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     memset(&va, 0, sizeof(va));
     va.N = N; va.node_stride = panel; va.R = R; va.Rhat = Rh; va.P = P; va.V = V; va.S = S; va.T = T;
     va.s = s; va.partial1 = part1; va.partial2 = part2; va.prec = prec;
+    va.counters = h->profiling ? h->d_counters : nullptr;
 
     void* Xk = X;        // the panel the Krylov recurrences update
     if (prec == 64) {
@@ -1530,11 +1531,12 @@ extern "C" int feasthip_profile_reset(feasthip_handle h) {
 extern "C" int feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms, int64_t* launches) {
     if (!h || !kernel_class) return FEASTHIP_ERROR_INTERNAL;
     fh_prof_collect(h);
-    if (!strcmp(kernel_class, "spmm.node_launches") || !strcmp(kernel_class, "spmm.column_passes")) {
-        unsigned long long c[2] = {0, 0};
+    if (!strcmp(kernel_class, "spmm.node_launches") || !strcmp(kernel_class, "spmm.column_passes") ||
+        !strcmp(kernel_class, "update.active_columns")) {
+        unsigned long long c[4] = {0, 0, 0, 0};
         hipStreamSynchronize(h->stream);
         hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost);
-        if (launches) *launches = (int64_t)c[kernel_class[5] == 'n' ? 0 : 1];
+        if (launches) *launches = (int64_t)c[kernel_class[0] == 'u' ? 2 : (kernel_class[5] == 'n' ? 0 : 1)];
         if (total_ms) *total_ms = 0.0;
         return 0;
     }

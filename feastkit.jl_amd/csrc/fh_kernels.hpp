@@ -35,6 +35,7 @@ struct fh_vec_args {
     fh_krylov_scalars s;
     cplx* partial1; cplx* partial2;
     int prec;                  // 64 | 32
+    unsigned long long* counters;   // measurement: [2] += active columns of this launch (update kernels), may be null
 };
 struct fh_fin_args {
     fh_krylov_scalars s;

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_xr_update(fh_vec_args a) {
     // X += alpha P + omega S ; R = S - omega T ; partial1 = <Rhat, R>, partial2 = <R, R>
     const int node = blockIdx.y;
     const int c = threadIdx.x % LD;
+    if (a.counters && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.counters + 2, (unsigned long long)a.s.node_active[node]);
     const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
     cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
     const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
@@ -600,6 +601,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
     // X += alpha P ; R -= alpha Q (Q stored in V) ; partial1 = sum R*R, partial2 = sum |R|^2
     const int node = blockIdx.y;
     const int c = threadIdx.x % LD;
+    if (a.counters && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.counters + 2, (unsigned long long)a.s.node_active[node]);
     const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
     cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
     const bool on = a.s.node_active[node] != 0 && a.s.active[node * LD + c];
