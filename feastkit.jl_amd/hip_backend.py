@@ -353,3 +353,78 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
             return FeastResult(lam[:M][order].copy(), X[:, :M][:, order].copy(), M, res[order].copy(), 0, epsout, loop, stats)
         loop += 1
         dQ = dX
+
+
+def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None, seed=20260515):
+    """Variant B ("moments") on the :hip engine -- the loop of the reference's parallel drivers
+    pfeast_sygv!/pfeast_scsrgv! (src/parallel/feast_parallel.jl:58-207, 450-572) with the
+    per-node worker pfeast_solve_sparse_single_point (:717-751) replaced by one
+    feasthip_contour_apply call that also returns the moment matrices
+        Aq = Re sum_e 2 w_e Q^T Y_e,   Sq = Re sum_e 2 w_e z_e Q^T Y_e,   Q_proj = Re sum_e 2 w_e Y_e.
+    Real-symmetric A, B only (as in the reference).  No orthonormalisation: the reduced pencil
+    (Sq, Aq) is solved as is and X = Q_proj V; all M0 columns are carried to the next loop.
+    The reference itself routes high-level dense calls away from this variant because it "does
+    not currently match serial results" (src/core/feast_backend_utils.jl:115); it is mirrored for
+    the seam, variant A (feast_hip_hermitian) is the robust path.
+    """
+    import scipy.sparse as _sp
+    N = A.shape[0]
+    feastdefault(fpm)
+    info = check_feast_srci_input(N, M0, Emin, Emax)
+    if info:
+        return FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), info, math.inf, 0)
+    rank, world = _world(group)
+    Bm = B if B is not None else (_sp.identity(N, format="csr") if _sp.issparse(A) else np.eye(N))
+    engine.set_problem(A, Bm)
+    Zne, Wne = feast_contour(Emin, Emax, fpm)
+    engine.set_contour(Zne, Wne, 2.0)
+    engine.set_real_projection(True)                      # real.(...) of feast_parallel.jl:38-55
+    first, count = distribute_contour_points(len(Zne), world)[rank]
+    engine.set_node_range(first, count)
+    engine.set_solver("direct" if not _sp.issparse(A) else "bicgstab", rtol=1e-13, atol=0.0, maxit=5000)
+    work = np.real(seeded_subspace(N, M0, seed)) if Q0 is None else np.real(np.asarray(Q0))
+    eps_tol = feast_tolerance(fpm)
+    max_loops = int(fpm[4])
+    lam = np.zeros(M0)
+    res = np.zeros(M0)
+    q = np.zeros((N, M0))
+    for loop in range(1, max_loops + 1):
+        dQ = engine.upload(work.astype(np.complex128))
+        dP, status, st, Aq, Sq = engine.contour_apply(dQ, M0, None, want_moments=True)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            engine.allreduce_sum(dP, group)
+            red = torch.tensor(np.stack([Aq.real, Sq.real]), dtype=torch.float64, device=dP.device)
+            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)      # feast_mpi.jl:117-119
+            Aq, Sq = red[0].cpu().numpy(), red[1].cpu().numpy()
+        Aq, Sq = np.real(Aq), np.real(Sq)
+        Q_proj = np.real(engine.download(dP, M0))
+        try:
+            Su = np.triu(Sq) + np.triu(Sq, 1).T               # Symmetric(X) reads the upper triangle
+            Au = np.triu(Aq) + np.triu(Aq, 1).T
+            lam_red, v_red = sla.eigh(Su, Au)
+        except Exception:
+            w_, v_red = sla.eig(Sq, Aq)
+            lam_red, v_red = np.real(w_), np.real(v_red)
+        q = Q_proj @ v_red
+        perm, M = _reorder_by_interval(lam_red, Emin, Emax, M0)
+        lam = np.asarray(lam_red)[perm]
+        q = q[:, perm]
+        if M == 0:
+            return FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), int(FeastError.Feast_ERROR_NO_CONVERGENCE), 0.0, loop)
+        for j in range(M):
+            nrm = np.linalg.norm(q[:, j])
+            if nrm > 0:
+                q[:, j] /= nrm
+        for j in range(M):                                    # feast_residual!, src/core/feast_tools.jl:726-755
+            r_ = A @ q[:, j] - lam[j] * (Bm @ q[:, j])
+            res[j] = np.linalg.norm(r_) / max(abs(lam[j]), 1.0)
+        epsout = float(res[:M].max())
+        if epsout <= eps_tol:
+            order = np.argsort(lam[:M], kind="stable")        # feast_sort!
+            return FeastResult(lam[:M][order].copy(), q[:, :M][:, order].copy(), M, res[:M][order].copy(), 0, epsout, loop)
+        work = q[:, :M0].copy()
+    M = int(sum(1 for i in range(M0) if Emin <= lam[i] <= Emax))
+    return FeastResult(lam[:M].copy(), q[:, :M].copy(), M, res[:M].copy(), int(FeastError.Feast_ERROR_NO_CONVERGENCE),
+                       float(res[:M].max()) if M else 0.0, max_loops)

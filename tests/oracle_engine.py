@@ -87,6 +87,15 @@ class OracleEngine:
         out[:m] = torch.from_numpy(np.ascontiguousarray(P.T))
         status = np.zeros(max(1, self.ne), dtype=np.int32)
         self.last_stats = {"krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0, "seconds_solve": 0.0}
+        if want_moments:
+            zA = np.zeros((m, m), dtype=np.complex128); zS = np.zeros((m, m), dtype=np.complex128)
+            for e in getattr(self, 'node_list', range(self.first, self.first + self.count)):
+                G = Q.conj().T @ self._solve(e, rhs)
+                zA += self.scale * self.Wne[e] * G
+                zS += self.scale * self.Wne[e] * self.Zne[e] * G
+            if self.real_projection:
+                zA, zS = zA.real.astype(np.complex128), zS.real.astype(np.complex128)
+            return out, status, self.last_stats, zA, zS
         return out, status, self.last_stats
 
     def orthonormalize(self, dQ, m, rank_tol):

@@ -312,3 +312,16 @@ def test_dense_generalized_real_symmetric_cfg2_variant(engine):
     r = fk.feast(A, B, (lo, hi), M0=32, fpm=fpm_with(f2=8), engine=engine)
     assert r.info == 0 and r.M == len(inside) and np.allclose(np.sort(r.lambda_), inside, atol=1e-10)
     assert r.epsout <= 1e-12
+
+
+def test_variant_b_moments_on_gpu(engine):
+    """Variant B through the C ABI (moments zAq/zSq from feasthip_contour_apply), the PFEAST fixture
+    of runtests.jl:1042-1089, dense (LU) and sparse (BiCGStab)."""
+    k = K["diag4_variant_b"]
+    A = np.diag(k["diag"]); B = np.eye(4)
+    for Ain, Bin in ((A, B), (sp.csr_matrix(A), sp.identity(4, format="csr"))):
+        r = fk.pfeast_hip_moments(engine, Ain, Bin, *k["interval"], 4, fpm_with(f2=k["fpm2"], f4=k["fpm4"]))
+        o = fo.pfeast_moments(sp.csc_matrix(Ain) if sp.issparse(Ain) else Ain, sp.csc_matrix(Bin) if sp.issparse(Bin) else Bin,
+                              *k["interval"], 4, ne=k["fpm2"], fpm4=k["fpm4"])
+        assert r.info == 0 == o.info and r.M == 3 == o.M
+        assert np.allclose(r.lambda_, k["expect_lambda"], atol=k["atol"]) and np.allclose(r.lambda_, o.lam, atol=1e-9)

@@ -214,3 +214,17 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     assert np.allclose(r0[4:4 + one.M], np.sort(one.lambda_), atol=1e-11)
     assert np.allclose(r0[4:4 + one.M], inside, atol=1e-10)
     assert int(r0[4 + one.M]) == 3
+
+
+def test_variant_b_moments_loop_equals_oracle():
+    """pfeast_hip_moments walks the reference's parallel 'moments' loop (feast_parallel.jl:450-572)."""
+    k = K["diag4_variant_b"]
+    A = np.diag(k["diag"]); B = np.eye(4)
+    for Ain, Bin in ((A, B), (sp.csr_matrix(A), sp.identity(4, format="csr"))):
+        fpm = fk.feastinit(); fpm[2], fpm[4] = k["fpm2"], k["fpm4"]
+        Q0 = np.real(fo.seeded_subspace(4, 4))
+        ref = fo.pfeast_moments(sp.csc_matrix(Ain) if sp.issparse(Ain) else Ain, sp.csc_matrix(Bin) if sp.issparse(Bin) else Bin,
+                                *k["interval"], 4, ne=k["fpm2"], fpm4=k["fpm4"], Q0=Q0.copy())
+        got = fk.pfeast_hip_moments(OracleEngine(), Ain, Bin, *k["interval"], 4, fpm, Q0=Q0.copy())
+        assert (got.info, got.M, got.loop) == (ref.info, ref.M, ref.loop) == (0, 3, ref.loop)
+        assert np.allclose(got.lambda_, ref.lam, atol=1e-12) and np.allclose(got.lambda_, k["expect_lambda"], atol=k["atol"])
