@@ -348,14 +348,79 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_gemm(cplx* const* LUs, int N, i
 }
 
 // ---- solve ------------------------------------------------------------------------------
-__global__ void k_build_perm(int* const* pivs, int* const* perms, int N) {
+// row permutation of the whole factorisation from the LAPACK-style pivot list, built once per
+// factorisation in LDS (N <= 16384) and cached behind the pivots: perm = pivs[q] + N
+__global__ __launch_bounds__(FH_BLOCK) void k_build_perm(int* const* pivs, int N) {
+    extern __shared__ int sperm[];
+    const int* piv = pivs[blockIdx.x];
+    int* perm = pivs[blockIdx.x] + N;
+    for (int i = threadIdx.x; i < N; i += FH_BLOCK) sperm[i] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < N; ++i) {
+            int p = piv[i];
+            if (p != i) { int u = sperm[i]; sperm[i] = sperm[p]; sperm[p] = u; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += FH_BLOCK) perm[i] = sperm[i];
+}
+
+// same, in global memory, for N beyond the LDS capacity
+__global__ void k_build_perm_global(int* const* pivs, int N) {
     if (threadIdx.x != 0) return;
     const int* piv = pivs[blockIdx.x];
-    int* perm = perms[blockIdx.x];
+    int* perm = pivs[blockIdx.x] + N;
     for (int i = 0; i < N; ++i) perm[i] = i;
     for (int i = 0; i < N; ++i) {
         int p = piv[i];
         if (p != i) { int u = perm[i]; perm[i] = perm[p]; perm[p] = u; }
+    }
+}
+
+// inverses of the NB x NB diagonal blocks of L (unit lower) and U, stored behind the factor:
+// inv = LU + N*N + (2*block + upper)*NB*NB, column-major, identity-padded in a short last
+// block.  The block triangular solves then become products (k_solve_step), which removes the
+// nb-step sequential substitution from the critical path of every block step.
+template <int NB>
+__global__ __launch_bounds__(64) void k_lu_invert_diag(cplx* const* LUs, int N) {
+    cplx* A = LUs[blockIdx.y];
+    const int k0 = blockIdx.x * NB;
+    const int nb = min(NB, N - k0);
+    cplx* inv = A + (size_t)N * N + (size_t)blockIdx.x * 2 * NB * NB;
+    __shared__ cplx T[NB][NB + 1];
+    __shared__ cplx Li[NB][NB + 1];
+    __shared__ cplx Ui[NB][NB + 1];
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 64) {
+        int i = e % NB, j = e / NB;
+        T[i][j] = (i < nb && j < nb) ? A[(size_t)(k0 + j) * N + k0 + i] : cmake(i == j ? 1.0 : 0.0, 0.0);
+        Li[i][j] = cmake(0, 0);
+        Ui[i][j] = cmake(0, 0);
+    }
+    __syncthreads();
+    if (t < NB) {                       // column t of L^-1
+        const int c = t;
+        Li[c][c] = cmake(1, 0);
+        for (int i = c + 1; i < NB; ++i) {
+            cplx s = cmake(0, 0);
+            for (int j = c; j < i; ++j) cfma(s, T[i][j], Li[j][c]);
+            Li[i][c] = cmake(-s.x, -s.y);
+        }
+    } else if (t < 2 * NB) {            // column c of U^-1
+        const int c = t - NB;
+        Ui[c][c] = cdiv(cmake(1, 0), T[c][c]);
+        for (int i = c - 1; i >= 0; --i) {
+            cplx s = cmake(0, 0);
+            for (int j = i + 1; j <= c; ++j) cfma(s, T[i][j], Ui[j][c]);
+            Ui[i][c] = cdiv(cmake(-s.x, -s.y), T[i][i]);
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 64) {
+        int i = e % NB, j = e / NB;
+        inv[e] = Li[i][j];
+        inv[NB * NB + e] = Ui[i][j];
     }
 }
 
@@ -371,64 +436,82 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gather_rows(const cplx* __restrict
     }
 }
 
-// in-place triangular solve of the nb x ld diagonal slab: lower (unit) or upper (non-unit)
-template <int NB, bool UPPER>
-__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(cplx* const* LUs, cplx* Y, size_t stride, int N, int ld,
-                                                          int k0, int nb) {
-    const cplx* A = LUs[blockIdx.x];
-    cplx* Yn = Y + (size_t)blockIdx.x * stride;
-    __shared__ cplx T[NB][NB + 1];
-    __shared__ cplx Ys[NB][FH_MAX_LD];
-    const int t = threadIdx.x;
-    for (int e = t; e < nb * nb; e += FH_BLOCK) {
-        int i = e % nb, j = e / nb;
-        T[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
-    }
-    for (int e = t; e < nb * ld; e += FH_BLOCK) Ys[e / ld][e % ld] = Yn[(size_t)(k0 + e / ld) * ld + e % ld];
-    __syncthreads();
-    if (t < ld) {
-        const int c = t;
-        if (!UPPER) {
-            for (int j = 0; j < nb; ++j) {
-                cplx xj = Ys[j][c];
-                for (int i = j + 1; i < nb; ++i) Ys[i][c] = csub(Ys[i][c], cmul(T[i][j], xj));
-            }
-        } else {
-            for (int j = nb - 1; j >= 0; --j) {
-                cplx xj = cdiv(Ys[j][c], T[j][j]);
-                Ys[j][c] = xj;
-                for (int i = 0; i < j; ++i) Ys[i][c] = csub(Ys[i][c], cmul(T[i][j], xj));
-            }
+// One block step of the triangular solves on row-major N x LD panels, one launch:
+//   Z[slab]  = T^-1 * IN[slab]                       (T^-1 from k_lu_invert_diag)
+//   IN[i,:] -= sum_j M[i, k0+j] Z[slab][j,:]         for i in [r0, r1)  (M = L below / U above)
+// Every workgroup recomputes the 32 x LD slab product (tiny) into LDS; workgroup x = 0 also
+// writes it to OUT.  The slab is read from IN and written to OUT, the updated rows are
+// disjoint from the slab, so no workgroup reads what another writes.  Forward: IN = Y (permuted
+// rhs), OUT = Z; backward: IN = Z, OUT = Y.  Both products run on v_mfma_f64_16x16x4_f64 with
+// operands straight from global memory (A operand = 16 consecutive rows of one factor column,
+// 256 B per 16 lanes); complex product with two accumulators: Re += ar*br + (-ai)*bi,
+// Im += ar*bi + ai*br.  Wave w owns the 16-row band w of the 64-row tile and all LD columns.
+template <int NB, int LD, bool UPPER>
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx* IN, cplx* OUT, size_t stride, int N,
+                                                          int k0, int r0, int r1) {
+    static_assert(NB == 32, "tile mapping assumes NB == 32");
+    const cplx* A = LUs[blockIdx.y];
+    const cplx* inv = A + (size_t)N * N + ((size_t)(k0 / NB) * 2 + (UPPER ? 1 : 0)) * NB * NB;
+    cplx* in = IN + (size_t)blockIdx.y * stride;
+    cplx* out = OUT + (size_t)blockIdx.y * stride;
+    __shared__ cplx Zs[NB][LD + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    constexpr int CT = LD / 16;
+    // ---- slab product
+    for (int q = wave; q < 2 * CT; q += 4) {
+        const int ti = q / CT, ta = q % CT;
+        lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < NB; kk += 4) {
+            const cplx a = inv[(size_t)(kk + lk) * NB + 16 * ti + lr];
+            const int row = k0 + kk + lk;
+            const cplx b = row < N ? in[(size_t)row * LD + 16 * ta + lr] : cmake(0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lk + 4 * r, c = 16 * ta + lr;
+            const cplx z = cmake(re[r], im[r]);
+            Zs[i][c] = z;
+            if (blockIdx.x == 0 && k0 + i < N) out[(size_t)(k0 + i) * LD + c] = z;
         }
     }
     __syncthreads();
-    for (int e = t; e < nb * ld; e += FH_BLOCK) Yn[(size_t)(k0 + e / ld) * ld + e % ld] = Ys[e / ld][e % ld];
-}
-
-// Y[i,:] -= sum_j M[i, k0+j] Y[k0+j,:]   for i in [r0, r1)   (M = L below / U above the slab)
-template <int NB, int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_solve_update(cplx* const* LUs, cplx* Y, size_t stride, int N, int k0,
-                                                            int nb, int r0, int r1) {
-    const cplx* A = LUs[blockIdx.y];
-    cplx* Yn = Y + (size_t)blockIdx.y * stride;
-    __shared__ cplx Ys[NB][LD];
-    __shared__ cplx Ms[NB][64 + 1];
-    const int t = threadIdx.x;
-    const int i0 = r0 + blockIdx.x * 64;
-    for (int e = t; e < nb * LD; e += FH_BLOCK) Ys[e / LD][e % LD] = Yn[(size_t)(k0 + e / LD) * LD + e % LD];
-    for (int e = t; e < nb * 64; e += FH_BLOCK) {
-        int ii = e % 64, j = e / 64;
-        Ms[j][ii] = (i0 + ii < r1) ? A[(size_t)(k0 + j) * N + i0 + ii] : cmake(0, 0);
+    // ---- update of this wave's 16-row band
+    const int ib = r0 + blockIdx.x * 64 + 16 * wave;
+    if (ib >= r1) return;
+    cplx am[NB / 4];
+#pragma unroll
+    for (int s = 0; s < NB / 4; ++s) {
+        const int col = k0 + 4 * s + lk;
+        am[s] = (ib + lr < r1 && col < N) ? A[(size_t)col * N + ib + lr] : cmake(0, 0);
     }
-    __syncthreads();
-    constexpr int RPP = FH_BLOCK / LD;     // rows per pass
-    const int c = t % LD, rr = t / LD;
-    for (int ii = rr; ii < 64; ii += RPP) {
-        const int i = i0 + ii;
-        if (i >= r1) break;
-        cplx acc = cmake(0, 0);
-        for (int j = 0; j < nb; ++j) cfma(acc, Ms[j][ii], Ys[j][c]);
-        Yn[(size_t)i * LD + c] = csub(Yn[(size_t)i * LD + c], acc);
+#pragma unroll
+    for (int ta = 0; ta < CT; ++ta) {
+        cplx y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ib + lk + 4 * r;
+            y[r] = i < r1 ? in[(size_t)i * LD + 16 * ta + lr] : cmake(0, 0);
+        }
+        lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NB / 4; ++s) {
+            const cplx b = Zs[4 * s + lk][16 * ta + lr];
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-am[s].y, b.y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.y, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].y, b.x, im, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ib + lk + 4 * r;
+            if (i < r1) in[(size_t)i * LD + 16 * ta + lr] = cmake(y[r].x - re[r], y[r].y - im[r]);
+        }
     }
 }
 
@@ -494,6 +577,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
             fh_prof_end(h);
         }
     }
+    fh_prof_begin(h, "lu_invert");
+    hipLaunchKernelGGL((k_lu_invert_diag<LU_NB>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, N);
+    if (N <= 16000) hipLaunchKernelGGL(k_build_perm, dim3(nf), dim3(FH_BLOCK), (size_t)N * sizeof(int), h->stream, dpvs, N);
+    else hipLaunchKernelGGL(k_build_perm_global, dim3(nf), dim3(64), 0, h->stream, dpvs, N);
+    fh_prof_end(h);
     info_out.assign(nf, 0);
     FH_CHECK(hipMemcpyAsync(info_out.data(), dinfo, nf * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
@@ -501,20 +589,17 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
 }
 
 template <int LD>
-static void lu_solve_launch(feasthip_ctx* h, cplx** dlus, cplx* Y, size_t stride, int N, int nf) {
-    for (int k0 = 0; k0 < N; k0 += LU_NB) {   // forward: L y = P b
-        const int nb = std::min(LU_NB, N - k0);
-        hipLaunchKernelGGL((k_solve_diag<LU_NB, false>), dim3(nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, stride, N, LD, k0, nb);
-        const int r0 = k0 + nb;
-        if (r0 < N)
-            hipLaunchKernelGGL((k_solve_update<LU_NB, LD>), dim3((N - r0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, stride, N, k0, nb, r0, N);
-    }
+static void lu_solve_launch(feasthip_ctx* h, cplx** dlus, cplx* Y, cplx* Z, size_t stride, int N, int nf) {
     const int nblocks = (N + LU_NB - 1) / LU_NB;
-    for (int b = nblocks - 1; b >= 0; --b) {   // backward: U x = y
-        const int k0 = b * LU_NB, nb = std::min(LU_NB, N - k0);
-        hipLaunchKernelGGL((k_solve_diag<LU_NB, true>), dim3(nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, stride, N, LD, k0, nb);
-        if (k0 > 0)
-            hipLaunchKernelGGL((k_solve_update<LU_NB, LD>), dim3((k0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, stride, N, k0, nb, 0, k0);
+    for (int b = 0; b < nblocks; ++b) {        // forward: L z = P b   (Y -> Z)
+        const int k0 = b * LU_NB, r0 = std::min(N, k0 + LU_NB);
+        const int gx = std::max(1, (N - r0 + 63) / 64);
+        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, false>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, k0, r0, N);
+    }
+    for (int b = nblocks - 1; b >= 0; --b) {   // backward: U x = z   (Z -> Y)
+        const int k0 = b * LU_NB;
+        const int gx = std::max(1, (k0 + 63) / 64);
+        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, true>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, k0, 0, k0);
     }
 }
 
@@ -524,26 +609,22 @@ static int lu_solve_batch(feasthip_ctx* h, int ld, const std::vector<int>& slots
     void* p;
     int rc;
     std::vector<cplx*> lus(nf);
-    std::vector<int*> pvs(nf), perms(nf);
-    if ((rc = fh_get_buf(h, "lu_perm", (size_t)nf * N * sizeof(int), &p))) return rc;
-    int* permbase = (int*)p;
-    for (int q = 0; q < nf; ++q) { lus[q] = (cplx*)h->lu_factors[slots[q]]; pvs[q] = h->lu_pivots[slots[q]]; perms[q] = permbase + (size_t)q * N; }
+    std::vector<int*> perms(nf);
+    for (int q = 0; q < nf; ++q) { lus[q] = (cplx*)h->lu_factors[slots[q]]; perms[q] = h->lu_pivots[slots[q]] + N; }
     if ((rc = fh_get_buf(h, "lu_ptrs", nf * sizeof(cplx*), &p))) return rc;
     cplx** dlus = (cplx**)p;
-    if ((rc = fh_get_buf(h, "lu_pptrs", nf * sizeof(int*), &p))) return rc;
-    int** dpvs = (int**)p;
     if ((rc = fh_get_buf(h, "lu_permptrs", nf * sizeof(int*), &p))) return rc;
     int** dperms = (int**)p;
+    if ((rc = fh_get_buf(h, "lu_zpanel", (size_t)nf * stride * sizeof(cplx), &p))) return rc;
+    cplx* Z = (cplx*)p;
     FH_CHECK(hipMemcpyAsync(dlus, lus.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
-    FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(dperms, perms.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_begin(h, "lu_solve");
-    hipLaunchKernelGGL(k_build_perm, dim3(nf), dim3(64), 0, h->stream, dpvs, dperms, N);
     hipLaunchKernelGGL(k_gather_rows, dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, dperms, Y, stride, N, ld);
-    if (ld == 16) lu_solve_launch<16>(h, dlus, Y, stride, N, nf);
-    else if (ld == 32) lu_solve_launch<32>(h, dlus, Y, stride, N, nf);
-    else lu_solve_launch<64>(h, dlus, Y, stride, N, nf);
+    if (ld == 16) lu_solve_launch<16>(h, dlus, Y, Z, stride, N, nf);
+    else if (ld == 32) lu_solve_launch<32>(h, dlus, Y, Z, stride, N, nf);
+    else lu_solve_launch<64>(h, dlus, Y, Z, stride, N, nf);
     fh_prof_end(h);
     return 0;
 }
@@ -552,8 +633,10 @@ static int lu_ensure_slots(feasthip_ctx* h, int nslots) {
     const size_t N = (size_t)h->dense.N;
     while ((int)h->lu_factors.size() < nslots) {
         void* f = nullptr; int* pv = nullptr;
-        FH_CHECK(hipMalloc(&f, N * N * sizeof(cplx)));
-        hipError_t e = hipMalloc((void**)&pv, N * sizeof(int));
+        // factor, then the inverted diagonal blocks (k_lu_invert_diag); pivots, then the row permutation
+        const size_t nblk = (N + LU_NB - 1) / LU_NB;
+        FH_CHECK(hipMalloc(&f, (N * N + nblk * 2 * LU_NB * LU_NB) * sizeof(cplx)));
+        hipError_t e = hipMalloc((void**)&pv, 2 * N * sizeof(int));
         if (e != hipSuccess) { hipFree(f); h->last_error = "hipMalloc(pivots)"; return FEASTHIP_ERROR_MEMORY; }
         h->lu_factors.push_back(f); h->lu_pivots.push_back(pv); h->lu_valid.push_back(0); h->lu_z.push_back(cmake(0, 0));
     }
