@@ -100,6 +100,8 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     feasthip_ctx* h = new (std::nothrow) feasthip_ctx();
     if (!h) return FEASTHIP_ERROR_MEMORY;
     h->device = device_id;
+    if (getenv("FH_LU_KB")) h->lu_outer_block = std::max(32, (atoi(getenv("FH_LU_KB")) / 32) * 32);
+    h->lu_panel_legacy = getenv("FH_LU_PANEL_LEGACY") ? atoi(getenv("FH_LU_PANEL_LEGACY")) : 0;
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
     h->stream = h->own_stream;

@@ -145,6 +145,8 @@ struct feasthip_ctx {
     std::vector<int*> lu_pivots;
     std::vector<int> lu_valid;
     std::vector<cplx> lu_z;
+    int lu_outer_block = 128;     // FH_LU_KB: outer block column of the two-level LU (multiple of 32)
+    int lu_panel_legacy = 0;      // FH_LU_PANEL_LEGACY=1: per-column global-memory panel kernel
 
     // host-mapped progress word written by the device: (chunk tag << 32) | active columns
     volatile unsigned long long* h_progress = nullptr;   // pinned host view

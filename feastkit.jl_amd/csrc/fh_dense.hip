@@ -227,25 +227,183 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(cplx* const* LUs,
     }
 }
 
-// apply the panel's row interchanges to the columns outside the panel
-__global__ __launch_bounds__(FH_BLOCK) void k_lu_laswp(cplx* const* LUs, int* const* pivs, int N, int k0, int nb) {
+// Register-resident panel factorisation.  One workgroup (1024 threads) per matrix; thread t
+// owns rows k0 + t + 1024 r (r < R) of the panel.  The nb panel columns are processed
+// left-looking in sub-panels of W columns (R*W = 16 complex values = 64 VGPRs per thread):
+//   1. U part of the sub-panel: forward substitution with the unit-lower block of the previous
+//      panel columns, in LDS (W threads);
+//   2. owned rows of the sub-panel are loaded into registers and updated with the previous
+//      columns (one coalesced read of each previous column, U part broadcast from LDS);
+//   3. the W columns are eliminated in registers: pivot search = per-thread max, wave shuffle
+//      reduction, 16-entry LDS reduction; pivot row and row jj exchanged through LDS; rank-1
+//      update in registers.  Two workgroup barriers per column and no global-memory traffic
+//      except the row interchange of the other panel columns.
+// Pivot rule as k_lu_panel (LAPACK IZAMAX).  Each panel entry is read from and written to
+// global memory once per sub-panel it participates in, instead of once per column.
+template <int R, int W>
+__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* LUs, int* const* pivs, int N, int k0,
+                                                                    int nb, int* info) {
+    cplx* A = LUs[blockIdx.x];
+    int* piv = pivs[blockIdx.x];
+    __shared__ double wmax[LU_PANEL_THREADS / 64];
+    __shared__ int widx[LU_PANEL_THREADS / 64];
+    __shared__ cplx rowA[W], rowB[W];
+    __shared__ cplx Lsm[LU_NB][LU_NB + 1];
+    __shared__ cplx Us[LU_NB][W];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int kend = k0 + nb;
+    int rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rows[r] = k0 + t + LU_PANEL_THREADS * r;
+
+    for (int c0 = k0; c0 < kend; c0 += W) {
+        const int pc = c0 - k0;                      // previous panel columns
+        const int wact = min(W, kend - c0);
+        // ---- 1. U part: Us = L11^-1 A[k0:c0, c0:c0+wact]
+        if (pc > 0) {
+            for (int e = t; e < pc * pc; e += LU_PANEL_THREADS) {
+                int i = e % pc, j = e / pc;
+                Lsm[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
+            }
+            for (int e = t; e < pc * wact; e += LU_PANEL_THREADS) {
+                int i = e % pc, w = e / pc;
+                Us[i][w] = A[(size_t)(c0 + w) * N + k0 + i];
+            }
+            __syncthreads();
+            if (t < wact) {
+                for (int i = 1; i < pc; ++i) {
+                    cplx x = Us[i][t];
+                    for (int j = 0; j < i; ++j) x = csub(x, cmul(Lsm[i][j], Us[j][t]));
+                    Us[i][t] = x;
+                }
+                for (int i = 0; i < pc; ++i) A[(size_t)(c0 + t) * N + k0 + i] = Us[i][t];
+            }
+            __syncthreads();
+        }
+        // ---- 2. load owned rows (>= c0) and apply the previous columns
+        cplx a[R][W];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                a[r][w] = (rows[r] >= c0 && rows[r] < N && w < wact) ? A[(size_t)(c0 + w) * N + rows[r]] : cmake(0, 0);
+        for (int p = 0; p < pc; ++p) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (rows[r] >= c0 && rows[r] < N) {
+                    const cplx l = A[(size_t)(k0 + p) * N + rows[r]];
+#pragma unroll
+                    for (int w = 0; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, Us[p][w]));
+                }
+            }
+        }
+        // ---- 3. eliminate the sub-panel columns in registers
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int jj = c0 + j;
+            if (jj < kend) {                          // uniform
+                double best = -1.0;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (rows[r] >= jj && rows[r] < N) {
+                        const double m = fabs(a[r][j].x) + fabs(a[r][j].y);
+                        if (m > best) { best = m; bi = rows[r]; }
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double o = __shfl_xor(best, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (o > best || (o == best && oi < bi)) { best = o; bi = oi; }
+                }
+                if (lane == 0) { wmax[wave] = best; widx[wave] = bi; }
+                __syncthreads();
+                best = wmax[0]; bi = widx[0];
+#pragma unroll
+                for (int q = 1; q < LU_PANEL_THREADS / 64; ++q) {
+                    const double o = wmax[q];
+                    const int oi = widx[q];
+                    if (o > best || (o == best && oi < bi)) { best = o; bi = oi; }
+                }
+                const int p = (bi == 0x7fffffff) ? jj : bi;
+                if (t == 0) {
+                    piv[jj] = p;
+                    if (!(best > 0.0) || !isfinite(best)) { if (info[blockIdx.x] == 0) info[blockIdx.x] = jj + 1; }
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (rows[r] == jj) {
+#pragma unroll
+                        for (int w = 0; w < W; ++w) rowA[w] = a[r][w];
+                    }
+                    if (rows[r] == p) {
+#pragma unroll
+                        for (int w = 0; w < W; ++w) rowB[w] = a[r][w];
+                    }
+                }
+                // the panel columns outside this sub-panel: interchange in global memory
+                if (p != jj && t < nb && (k0 + t < c0 || k0 + t >= c0 + W)) {
+                    cplx u = A[(size_t)(k0 + t) * N + jj];
+                    A[(size_t)(k0 + t) * N + jj] = A[(size_t)(k0 + t) * N + p];
+                    A[(size_t)(k0 + t) * N + p] = u;
+                }
+                __syncthreads();
+                const cplx pv = rowB[j];
+                const bool singular = (pv.x == 0.0 && pv.y == 0.0);
+                const cplx inv = singular ? cmake(0, 0) : cdiv(cmake(1, 0), pv);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (p != jj) {
+                        if (rows[r] == jj) {
+#pragma unroll
+                            for (int w = 0; w < W; ++w) a[r][w] = rowB[w];
+                        } else if (rows[r] == p) {
+#pragma unroll
+                            for (int w = 0; w < W; ++w) a[r][w] = rowA[w];
+                        }
+                    }
+                    if (rows[r] > jj && rows[r] < N) {
+                        const cplx l = cmul(a[r][j], inv);
+                        a[r][j] = l;
+#pragma unroll
+                        for (int w = j + 1; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, rowB[w]));
+                    }
+                }
+            }
+        }
+        // ---- store rows >= c0 of the sub-panel
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                if (rows[r] >= c0 && rows[r] < N && w < wact) A[(size_t)(c0 + w) * N + rows[r]] = a[r][w];
+        __syncthreads();
+    }
+}
+
+// apply the row interchanges piv[p0 .. p0+np) to the columns [a0,a1) and [b0,b1)
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_laswp(cplx* const* LUs, int* const* pivs, int N, int p0, int np,
+                                                        int a0, int a1, int b0, int b1) {
     cplx* A = LUs[blockIdx.y];
     const int* piv = pivs[blockIdx.y];
-    const int c = blockIdx.x * FH_BLOCK + threadIdx.x;
-    if (c >= N || (c >= k0 && c < k0 + nb)) return;
-    for (int j = 0; j < nb; ++j) {
-        int p = piv[k0 + j];
-        if (p != k0 + j) {
-            cplx u = A[(size_t)c * N + k0 + j];
-            A[(size_t)c * N + k0 + j] = A[(size_t)c * N + p];
+    const int id = blockIdx.x * FH_BLOCK + threadIdx.x;
+    const int na = a1 - a0;
+    const int c = id < na ? a0 + id : b0 + (id - na);
+    if (c >= b1) return;
+    for (int j = 0; j < np; ++j) {
+        int p = piv[p0 + j];
+        if (p != p0 + j) {
+            cplx u = A[(size_t)c * N + p0 + j];
+            A[(size_t)c * N + p0 + j] = A[(size_t)c * N + p];
             A[(size_t)c * N + p] = u;
         }
     }
 }
 
-// U12 = L11^{-1} A12 : one thread per trailing column
+// U block row: A[k0:k0+NB, c] = L11^{-1} A[k0:k0+NB, c] for columns c in [c0,c1); one thread per column
 template <int NB>
-__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, int k0) {
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, int k0, int c0, int c1) {
     cplx* A = LUs[blockIdx.y];
     __shared__ cplx L[NB][NB + 1];
     for (int e = threadIdx.x; e < NB * NB; e += FH_BLOCK) {
@@ -253,8 +411,8 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, i
         L[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
     }
     __syncthreads();
-    const int c = k0 + NB + blockIdx.x * FH_BLOCK + threadIdx.x;
-    if (c >= N) return;
+    const int c = c0 + blockIdx.x * FH_BLOCK + threadIdx.x;
+    if (c >= c1) return;
     cplx x[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) x[i] = A[(size_t)c * N + k0 + i];
@@ -267,27 +425,100 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, i
     for (int i = 0; i < NB; ++i) A[(size_t)c * N + k0 + i] = x[i];
 }
 
-// A22 -= L21 U12 on v_mfma_f64_16x16x4_f64: 64x64 tile of A22 per workgroup, four waves as
-// 2x2 of 32x32, each wave 2x2 MFMA tiles.  The product is formed TRANSPOSED,
-//     D[c][i] = sum_k U[k][c] * L[i][k]      (A operand = U^T, B operand = L^T)
+// A[r0:r1, c0:c1] -= A[r0:r1, k0:k0+kd] * A[k0:k0+kd, c0:c1]  (kd a multiple of KC = 32) on
+// v_mfma_f64_16x16x4_f64: 64x64 tile per workgroup, four waves as 2x2 of 32x32, each wave
+// 2x2 MFMA tiles; the k range is walked in chunks of KC through LDS.  The product is formed
+// TRANSPOSED,   D[c][i] = sum_k U[k][c] * L[i][k]      (A operand = U^T, B operand = L^T)
 // so that a lane's results (row = (l>>4)+4r -> c, col = l&15 -> i) are 16 consecutive rows of
-// one column of the column-major trailing matrix: 256 B contiguous per 16-lane group.
-// Complex product from four real MFMAs per tile: rr, ii, ri, ir;  Re = rr - ii, Im = ri + ir.
+// one column of the column-major matrix: 256 B contiguous per 16-lane group.
+// Complex product with two accumulators per tile: Re += ur*lr + (-ui)*li, Im += ur*li + ui*lr.
+// The two-level factorisation calls it with kd = 32 inside an outer block column and kd = 128
+// for the trailing matrix, which is then read and written once per 128 eliminated columns.
 typedef double lu_v4d __attribute__((ext_vector_type(4)));
 
-template <int NB>
-__global__ __launch_bounds__(FH_BLOCK) void k_lu_gemm(cplx* const* LUs, int N, int k0) {
-    cplx* A = LUs[blockIdx.z];
-    __shared__ cplx Ls[NB][64];
-    __shared__ cplx Us[NB][64];
+template <int KC>
+__global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
+                                                       int c1, int TR, int TC) {
+    cplx* A = LUs[blockIdx.y];
+    __shared__ cplx Ls[KC][64];
+    __shared__ cplx Us[KC][64];
     const int t = threadIdx.x;
-    const int base = k0 + NB;
-    const int i0 = base + blockIdx.x * 64, c0 = base + blockIdx.y * 64;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so XCD x takes the
+    // 8x8 super-tiles x, x+8, ... and walks one super-tile with 64 consecutive local slots:
+    // its L2 then holds the 8 L row tiles and <= 8 U column tiles (2 MB at k = 128) being reused
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int SR = (TR + 7) >> 3;
+    const int sw = min(8, TC);                                 // super-tile: 8 row tiles x sw column tiles
+    const int st = (slot / (8 * sw)) * 8 + xcd, within = slot % (8 * sw);
+    const int tr = (st % SR) * 8 + (within & 7), tc = (st / SR) * sw + (within >> 3);
+    if (tr >= TR || tc >= TC) return;
+    const int i0 = r0 + tr * 64, cc0 = c0 + tc * 64;
     const int lane = t & 63, wave = t >> 6;
     const int wi = (wave & 1) * 32, wc = (wave >> 1) * 32;     // wave's 32x32 sub-tile
     const int lr = lane & 15, lk = lane >> 4;
-    // issue the read of this lane's 16 trailing-matrix entries first: it overlaps the LDS fill
-    // and the MFMA loop instead of sitting exposed in front of the read-modify-write
+    constexpr int PF = KC * 64 / FH_BLOCK;                     // panel entries per thread and chunk
+    cplx pl[PF], pu[PF];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = t + q * FH_BLOCK;
+            const int ii = e % 64, kl = e / 64;
+            pl[q] = (i0 + ii < r1) ? A[(size_t)(k0 + kc + kl) * N + i0 + ii] : cmake(0, 0);
+            const int ku = e % KC, cc = e / KC;
+            pu[q] = (cc0 + cc < c1) ? A[(size_t)(cc0 + cc) * N + k0 + kc + ku] : cmake(0, 0);
+        }
+    };
+    fetch(0);
+    lu_v4d re[2][2], im[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { re[a][b] = (lu_v4d){0, 0, 0, 0}; im[a][b] = re[a][b]; }
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = t + q * FH_BLOCK;
+            Ls[e / 64][e % 64] = pl[q];
+            Us[e % KC][e / KC] = pu[q];
+        }
+    };
+    auto mma = [&]() {
+#pragma unroll 2
+        for (int kk = 0; kk < KC; kk += 4) {
+            cplx u[2], l[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) u[a] = Us[kk + lk][wc + 16 * a + lr];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) l[b] = Ls[kk + lk][wi + 16 * b + lr];
+            // four sweeps over the 2x2 tiles: dependent MFMAs on one accumulator are 8 issues apart
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].x, re[a][b], 0, 0, 0);
+                    im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].y, im[a][b], 0, 0, 0);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-u[a].y, l[b].y, re[a][b], 0, 0, 0);
+                    im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].y, l[b].x, im[a][b], 0, 0, 0);
+                }
+        }
+    };
+    int kc = 0;
+    for (; kc + KC < kd; kc += KC) {
+        if (kc) __syncthreads();
+        stage();
+        __syncthreads();
+        fetch(kc + KC);                            // next chunk's loads fly under this chunk's MFMAs
+        mma();
+    }
+    // last chunk: the panel registers are free, this lane's 16 matrix entries take their place
+    if (kc) __syncthreads();
+    stage();
+    __syncthreads();
     cplx cv[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -295,53 +526,23 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_gemm(cplx* const* LUs, int N, i
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = c0 + wc + 16 * a + lk + 4 * r;
+                const int c = cc0 + wc + 16 * a + lk + 4 * r;
                 const int i = i0 + wi + 16 * b + lr;
-                cv[a][b][r] = (i < N && c < N) ? A[(size_t)c * N + i] : cmake(0, 0);
+                cv[a][b][r] = (i < r1 && c < c1) ? A[(size_t)c * N + i] : cmake(0, 0);
             }
-    for (int e = t; e < NB * 64; e += FH_BLOCK) {
-        int ii = e % 64, k = e / 64;
-        Ls[k][ii] = (i0 + ii < N) ? A[(size_t)(k0 + k) * N + i0 + ii] : cmake(0, 0);
-    }
-    for (int e = t; e < NB * 64; e += FH_BLOCK) {
-        int k = e % NB, cc = e / NB;
-        Us[k][cc] = (c0 + cc < N) ? A[(size_t)(c0 + cc) * N + k0 + k] : cmake(0, 0);
-    }
-    __syncthreads();
-    lu_v4d rr[2][2], ii[2][2], ri[2][2], ir[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) { rr[a][b] = (lu_v4d){0, 0, 0, 0}; ii[a][b] = rr[a][b]; ri[a][b] = rr[a][b]; ir[a][b] = rr[a][b]; }
-#pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-        cplx u[2], l[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) u[a] = Us[kk + lk][wc + 16 * a + lr];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) l[b] = Ls[kk + lk][wi + 16 * b + lr];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                rr[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].x, rr[a][b], 0, 0, 0);
-                ii[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].y, l[b].y, ii[a][b], 0, 0, 0);
-                ri[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].y, ri[a][b], 0, 0, 0);
-                ir[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].y, l[b].x, ir[a][b], 0, 0, 0);
-            }
-    }
+    mma();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = c0 + wc + 16 * a + lk + 4 * r;
+                const int c = cc0 + wc + 16 * a + lk + 4 * r;
                 const int i = i0 + wi + 16 * b + lr;
-                if (i < N && c < N) {
+                if (i < r1 && c < c1) {
                     cplx v = cv[a][b][r];
-                    v.x -= rr[a][b][r] - ii[a][b][r];
-                    v.y -= ri[a][b][r] + ir[a][b][r];
+                    v.x -= re[a][b][r];
+                    v.y -= im[a][b][r];
                     A[(size_t)c * N + i] = v;
                 }
             }
@@ -448,7 +649,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gather_rows(const cplx* __restrict
 // Im += ar*bi + ai*br.  Wave w owns the 16-row band w of the 64-row tile and all LD columns.
 template <int NB, int LD, bool UPPER>
 __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx* IN, cplx* OUT, size_t stride, int N,
-                                                          int k0, int r0, int r1) {
+                                                          int k0, int r0, int r1, int rb, int cta) {
     static_assert(NB == 32, "tile mapping assumes NB == 32");
     const cplx* A = LUs[blockIdx.y];
     const cplx* inv = A + (size_t)N * N + ((size_t)(k0 / NB) * 2 + (UPPER ? 1 : 0)) * NB * NB;
@@ -459,8 +660,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx*
     const int lr = lane & 15, lk = lane >> 4;
     constexpr int CT = LD / 16;
     // ---- slab product
-    for (int q = wave; q < 2 * CT; q += 4) {
-        const int ti = q / CT, ta = q % CT;
+    // cta = column tiles that hold active right-hand sides (the rest of the panel is padding)
+    for (int q = wave; q < 2 * cta; q += 4) {
+        const int ti = q / cta, ta = q % cta;
         lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
 #pragma unroll
         for (int kk = 0; kk < NB; kk += 4) {
@@ -481,36 +683,39 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx*
         }
     }
     __syncthreads();
-    // ---- update of this wave's 16-row band
-    const int ib = r0 + blockIdx.x * 64 + 16 * wave;
-    if (ib >= r1) return;
-    cplx am[NB / 4];
-#pragma unroll
-    for (int s = 0; s < NB / 4; ++s) {
-        const int col = k0 + 4 * s + lk;
-        am[s] = (ib + lr < r1 && col < N) ? A[(size_t)col * N + ib + lr] : cmake(0, 0);
-    }
-#pragma unroll
-    for (int ta = 0; ta < CT; ++ta) {
-        cplx y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = ib + lk + 4 * r;
-            y[r] = i < r1 ? in[(size_t)i * LD + 16 * ta + lr] : cmake(0, 0);
-        }
-        lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+    // ---- update: the workgroup owns 64*rb rows, wave w the 16-row bands w, w+4, ...
+    for (int band = wave; band < 4 * rb; band += 4) {
+        const int ib = r0 + (blockIdx.x * 4 * rb + band) * 16;
+        if (ib >= r1) break;
+        cplx am[NB / 4];
 #pragma unroll
         for (int s = 0; s < NB / 4; ++s) {
-            const cplx b = Zs[4 * s + lk][16 * ta + lr];
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.x, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-am[s].y, b.y, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.y, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].y, b.x, im, 0, 0, 0);
+            const int col = k0 + 4 * s + lk;
+            am[s] = (ib + lr < r1 && col < N) ? A[(size_t)col * N + ib + lr] : cmake(0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = ib + lk + 4 * r;
-            if (i < r1) in[(size_t)i * LD + 16 * ta + lr] = cmake(y[r].x - re[r], y[r].y - im[r]);
+        for (int ta = 0; ta < CT; ++ta) {
+            if (ta >= cta) break;
+            cplx y[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ib + lk + 4 * r;
+                y[r] = i < r1 ? in[(size_t)i * LD + 16 * ta + lr] : cmake(0, 0);
+            }
+            lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NB / 4; ++s) {
+                const cplx b = Zs[4 * s + lk][16 * ta + lr];
+                re = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.x, re, 0, 0, 0);
+                re = __builtin_amdgcn_mfma_f64_16x16x4f64(-am[s].y, b.y, re, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.y, im, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].y, b.x, im, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ib + lk + 4 * r;
+                if (i < r1) in[(size_t)i * LD + 16 * ta + lr] = cmake(y[r].x - re[r], y[r].y - im[r]);
+            }
         }
     }
 }
@@ -557,24 +762,61 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         }
         fh_prof_end(h);
     }
-    for (int k0 = 0; k0 < N; k0 += LU_NB) {
-        const int nb = std::min(LU_NB, N - k0);
-        fh_prof_begin(h, "lu_panel");
-        hipLaunchKernelGGL(k_lu_panel, dim3(nf), dim3(LU_PANEL_THREADS), 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-        fh_prof_end(h);
+    // two-level right-looking LU: outer block columns of LU_KB = 4 LU_NB; inside one, the
+    // LU_NB-wide panels update only the block column (k = 32 products on N x <=96), and the
+    // trailing matrix gets one k = LU_KB product per block column
+    auto laswp = [&](int p0, int np, int a0, int a1, int b0, int b1) {
+        const int ncols = (a1 - a0) + (b1 - b0);
+        if (ncols <= 0) return;
         fh_prof_begin(h, "lu_laswp");
-        hipLaunchKernelGGL(k_lu_laswp, dim3((N + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, dpvs, N, k0, nb);
+        hipLaunchKernelGGL(k_lu_laswp, dim3((ncols + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, dpvs, N, p0, np, a0, a1, b0, b1);
         fh_prof_end(h);
-        const int rest = N - k0 - nb;
-        if (rest > 0) {
-            // nb == LU_NB here (a short last panel has no trailing matrix)
-            fh_prof_begin(h, "lu_trsm");
-            hipLaunchKernelGGL((k_lu_trsm<LU_NB>), dim3((rest + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0);
+    };
+    auto trsm = [&](int k0, int c0, int c1) {
+        fh_prof_begin(h, "lu_trsm");
+        hipLaunchKernelGGL((k_lu_trsm<LU_NB>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
+        fh_prof_end(h);
+    };
+    auto gemm = [&](int k0, int kd, int r0, int r1, int c0, int c1, const char* cls) {
+        if (r1 <= r0 || c1 <= c0) return;
+        fh_prof_begin(h, cls);
+        const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
+        const int sw = std::min(8, TC);
+        const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
+        hipLaunchKernelGGL((k_lu_gemm<LU_NB>), dim3(((nsuper + 7) / 8) * 8 * 8 * sw, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+        fh_prof_end(h);
+    };
+    const int KB = h->lu_outer_block;
+    for (int K0 = 0; K0 < N; K0 += KB) {
+        const int Kend = std::min(N, K0 + KB);
+        for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
+            const int nb = std::min(LU_NB, Kend - k0);
+            fh_prof_begin(h, "lu_panel");
+            {
+                const int nrows = N - k0;
+                const dim3 g(nf), b(LU_PANEL_THREADS);
+                if (h->lu_panel_legacy || nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL(k_lu_panel, g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+            }
             fh_prof_end(h);
-            const int tiles = (rest + 63) / 64;
-            fh_prof_begin(h, "lu_gemm");
-            hipLaunchKernelGGL((k_lu_gemm<LU_NB>), dim3(tiles, tiles, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0);
-            fh_prof_end(h);
+            // interchanges inside the block column (left: finished L columns, right: still to eliminate)
+            laswp(k0, nb, K0, k0, k0 + nb, Kend);
+            if (k0 + nb < Kend) {     // nb == LU_NB here
+                trsm(k0, k0 + nb, Kend);
+                gemm(k0, LU_NB, k0 + nb, N, k0 + nb, Kend, "lu_gemm_in");
+            }
+        }
+        // the block column's interchanges on everything outside it
+        laswp(K0, Kend - K0, 0, K0, Kend, N);
+        if (Kend < N) {               // Kend - K0 == KB here
+            for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
+                trsm(k0, Kend, N);
+                gemm(k0, LU_NB, k0 + LU_NB, Kend, Kend, N, "lu_gemm_in");
+            }
+            gemm(K0, KB, Kend, N, Kend, N, "lu_gemm");
         }
     }
     fh_prof_begin(h, "lu_invert");
@@ -588,22 +830,32 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     return 0;
 }
 
+// rows per workgroup (in units of 64): enough workgroups to fill the chip, few enough that the
+// per-workgroup slab product is amortised
+static int lu_solve_rb(int rows, int nf) {
+    int rb = (int)(((long long)rows * nf) / (64LL * 768));
+    return std::max(1, std::min(8, rb));
+}
+
 template <int LD>
-static void lu_solve_launch(feasthip_ctx* h, cplx** dlus, cplx* Y, cplx* Z, size_t stride, int N, int nf) {
+static void lu_solve_launch(feasthip_ctx* h, cplx** dlus, cplx* Y, cplx* Z, size_t stride, int N, int nf, int m) {
+    const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
     const int nblocks = (N + LU_NB - 1) / LU_NB;
     for (int b = 0; b < nblocks; ++b) {        // forward: L z = P b   (Y -> Z)
         const int k0 = b * LU_NB, r0 = std::min(N, k0 + LU_NB);
-        const int gx = std::max(1, (N - r0 + 63) / 64);
-        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, false>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, k0, r0, N);
+        const int rb = lu_solve_rb(N - r0, nf);
+        const int gx = std::max(1, (N - r0 + 64 * rb - 1) / (64 * rb));
+        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, false>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, k0, r0, N, rb, cta);
     }
     for (int b = nblocks - 1; b >= 0; --b) {   // backward: U x = z   (Z -> Y)
         const int k0 = b * LU_NB;
-        const int gx = std::max(1, (k0 + 63) / 64);
-        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, true>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, k0, 0, k0);
+        const int rb = lu_solve_rb(k0, nf);
+        const int gx = std::max(1, (k0 + 64 * rb - 1) / (64 * rb));
+        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, true>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, k0, 0, k0, rb, cta);
     }
 }
 
-static int lu_solve_batch(feasthip_ctx* h, int ld, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
+static int lu_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
     const int nf = (int)slots.size();
     const int N = (int)h->dense.N;
     void* p;
@@ -622,9 +874,9 @@ static int lu_solve_batch(feasthip_ctx* h, int ld, const std::vector<int>& slots
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_begin(h, "lu_solve");
     hipLaunchKernelGGL(k_gather_rows, dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, dperms, Y, stride, N, ld);
-    if (ld == 16) lu_solve_launch<16>(h, dlus, Y, Z, stride, N, nf);
-    else if (ld == 32) lu_solve_launch<32>(h, dlus, Y, Z, stride, N, nf);
-    else lu_solve_launch<64>(h, dlus, Y, Z, stride, N, nf);
+    if (ld == 16) lu_solve_launch<16>(h, dlus, Y, Z, stride, N, nf, m);
+    else if (ld == 32) lu_solve_launch<32>(h, dlus, Y, Z, stride, N, nf, m);
+    else lu_solve_launch<64>(h, dlus, Y, Z, stride, N, nf, m);
     fh_prof_end(h);
     return 0;
 }
@@ -645,7 +897,6 @@ static int lu_ensure_slots(feasthip_ctx* h, int nslots) {
 
 int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
                             cplx* Y, size_t stride, std::vector<int>& status, int64_t* nfact) {
-    (void)m;
     int rc = lu_ensure_slots(h, nodes);
     if (rc) return rc;
     std::vector<int> need;
@@ -663,14 +914,13 @@ int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std
     if (nfact) *nfact = (int64_t)need.size();
     std::vector<int> slots(nodes);
     for (int e = 0; e < nodes; ++e) slots[e] = e;
-    if ((rc = lu_solve_batch(h, ld, slots, RHS, Y, stride))) return rc;
+    if ((rc = lu_solve_batch(h, ld, m, slots, RHS, Y, stride))) return rc;
     status.assign(nodes, 0);
     for (int e = 0; e < nodes; ++e) if (h->lu_valid[e] != 1) status[e] = FEASTHIP_ERROR_LAPACK;
     return 0;
 }
 
 int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status, int64_t* nfact) {
-    (void)m;
     // uses a dedicated extra slot after the node slots
     const int slot = h->node_count;
     int rc = lu_ensure_slots(h, slot + 1);
@@ -684,7 +934,7 @@ int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx*
         h->lu_valid[slot] = info[0] == 0 ? 1 : -1;
         if (nfact) *nfact = 1;
     }
-    if ((rc = lu_solve_batch(h, ld, need, RHS, Y, (size_t)h->dense.N * ld))) return rc;
+    if ((rc = lu_solve_batch(h, ld, m, need, RHS, Y, (size_t)h->dense.N * ld))) return rc;
     *status = h->lu_valid[slot] == 1 ? 0 : FEASTHIP_ERROR_LAPACK;
     return 0;
 }
