@@ -1,0 +1,23 @@
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import numpy as np
+import feastkit_jl_amd as fk
+import feast_oracle as fo
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+A = fo.householder_conjugated_diag(0.01 * np.arange(N))
+eng = fk.HipEngine(0)
+for rep in range(2):
+    fpm = fk.feastinit(); fpm[2] = 8
+    eng.profile_reset(); eng.profile_enable(True)
+    t0 = time.perf_counter()
+    lo = 0.01 * (N // 4) - 0.005
+    r = fk.feast_hip_hermitian(eng, A, None, lo, lo + 0.2, 32, fpm, solver="direct")
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+    want = 0.01 * np.arange(N // 4, N // 4 + 20)
+    err = np.abs(np.sort(r.lambda_) - want).max() if r.M == 20 else None
+    print(f"N={N}: info={r.info} M={r.M} loops={r.loop} epsout={r.epsout:.2e} eigerr={err} time={dt:.3f}s phases={ {k: round(v,3) for k,v in r.stats['phase_seconds'].items()} }")
+    for cls in ("lu_form", "lu_panel", "lu_laswp", "lu_trsm", "lu_gemm_in", "lu_gemm", "lu_invert", "lu_solve", "dense_op", "ortho", "gram"):
+        ms, n = eng.profile_get(cls)
+        if n: print(f"   {cls:10s} launches {n:5d} est total {ms:9.2f} ms")
