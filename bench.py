@@ -27,22 +27,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/
 
 def build_problem():
     """7-point Dirichlet Laplacian on 50x40x25 (x fastest), B = I + 0.1 A; closed-form spectrum."""
-    import numpy as np
-    import scipy.sparse as sp
-
-    def t(n):
-        return sp.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
-    nx, ny, nz = 50, 40, 25
-    Ix, Iy, Iz = sp.identity(nx), sp.identity(ny), sp.identity(nz)
-    A = sp.csr_matrix(sp.kron(Iz, sp.kron(Iy, t(nx))) + sp.kron(Iz, sp.kron(t(ny), Ix)) + sp.kron(t(nz), sp.kron(Iy, Ix)))
-    A.sort_indices()
-    B = sp.csr_matrix(sp.identity(A.shape[0], format="csr") + 0.1 * A)
-    B.sort_indices()
-    mx = 2 - 2 * np.cos(np.arange(1, nx + 1) * np.pi / (nx + 1))
-    my = 2 - 2 * np.cos(np.arange(1, ny + 1) * np.pi / (ny + 1))
-    mz = 2 - 2 * np.cos(np.arange(1, nz + 1) * np.pi / (nz + 1))
-    mu = np.sort((mx[:, None, None] + my[None, :, None] + mz[None, None, :]).ravel())
-    return A, B, np.sort(mu / (1 + 0.1 * mu))
+    import feastkit_jl_amd as fk
+    return fk.workloads.laplacian_3d_pencil(50, 40, 25, 0.1)
 
 
 def cpu_baseline(A, B, n_inside):

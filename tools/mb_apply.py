@@ -1,20 +1,21 @@
+"""Fixed-iteration contour_apply on cfg 3 for kernel timing / PMC passes.
+Usage: python tools/mb_apply.py [nodes] [iterations] [reps]   (env SOLVER, PREC)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
 import numpy as np
 import feastkit_jl_amd as fk
-import feast_oracle as fo
 nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 maxit = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-A, B, lam = fo.cfg3_problem(50, 40, 25)
+A, B, lam = fk.workloads.laplacian_3d_pencil(50, 40, 25)
 eng = fk.HipEngine(0)
 eng.set_problem(A, B)
-Z, W = fo.feast_contour(0.0, 0.1775, 16)
+Z, W = fk.feast_contour(0.0, 0.1775, 16)
 eng.set_contour(Z, W, 2.0)
 eng.set_node_range(0, nodes)
 eng.set_solver(os.environ.get("SOLVER","bicgstab"), rtol=0.0, atol=0.0, maxit=maxit, factor_precision=int(os.environ.get("PREC","64")))
-Q = eng.upload(fo.seeded_subspace(50000, 64))
+Q = eng.upload(fk.seeded_subspace(50000, 64))
 eng.contour_apply(Q, 64)
 eng.profile_reset(); eng.profile_enable(True)
 t0 = time.perf_counter()

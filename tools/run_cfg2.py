@@ -1,11 +1,12 @@
+"""cfg 2 at full size on one GPU: dense symmetric N=4096 (default), 8 Gauss nodes, M0=32, direct solves.
+Usage: python tools/run_cfg2.py [N]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
 import numpy as np
 import feastkit_jl_amd as fk
-import feast_oracle as fo
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-A = fo.householder_conjugated_diag(0.01 * np.arange(N))
+A = fk.workloads.reflected_diagonal(0.01 * np.arange(N))
 eng = fk.HipEngine(0)
 for rep in range(2):
     fpm = fk.feastinit(); fpm[2] = 8

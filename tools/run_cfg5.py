@@ -1,22 +1,13 @@
+"""cfg 5 at full size on one GPU: complex non-Hermitian N=8192, centre 0 radius 2, 24 nodes, M0=48.
+Usage: python tools/run_cfg5.py [N] [ne]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, ROOT)
 import numpy as np
 import feastkit_jl_amd as fk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 ne = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-rng = np.random.default_rng(20260515)
-rad = 33.05 * np.sqrt(N / 8192.0) * np.sqrt(rng.random(N))
-delta = rad * np.exp(2j * np.pi * rng.random(N))
-U = np.triu(rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N)), 1) / np.sqrt(N)
-T = np.diag(delta) + 0.05 * U
-del U
-def refl(M, v):
-    Mv = M @ v; M -= 2 * np.outer(Mv, v.conj()); vM = v.conj() @ M; M -= 2 * np.outer(v, vM); return M
-for _ in range(2):
-    v = rng.standard_normal(N) + 1j * rng.standard_normal(N); v /= np.linalg.norm(v)
-    T = refl(T, v)
-A = T
+A, delta = fk.workloads.disc_spectrum_general(N)
 inside = delta[np.abs(delta) <= 2.0]
 print("N", N, "inside", len(inside), flush=True)
 eng = fk.HipEngine(0)
