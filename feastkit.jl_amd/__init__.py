@@ -15,5 +15,8 @@ from . import workloads   # noqa: F401
 from .hip_backend import feast_hip_hermitian, feast_hip_general, pfeast_hip_moments, seeded_subspace   # noqa: F401
 from .engine import HipEngine   # noqa: F401
 from .api import feast, feast_general   # noqa: F401
+from . import rci   # noqa: F401
+from .rci import (RciRefs, RciState, HipRciServer, feast_srci, feast_hrci, feast_grci,   # noqa: F401
+                  rci_solve_symmetric, rci_solve_hermitian, rci_solve_general)
 
 __version__ = "0.1.0"

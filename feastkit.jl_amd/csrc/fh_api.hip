@@ -1458,7 +1458,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
     if (h->solver == FEASTHIP_SOLVER_LU) {
         if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix"; return FEASTHIP_ERROR_FPM; }
         int64_t nfact = 0;
-        // one-off factorisation, not cached (node index -1)
+        // cached per quadrature node when z is one, else in one extra slot
         rc = fh_dense_lu_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;
         if (stats) stats->factorizations = nfact;

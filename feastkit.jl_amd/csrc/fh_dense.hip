@@ -921,9 +921,16 @@ int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std
 }
 
 int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status, int64_t* nfact) {
-    // uses a dedicated extra slot after the node slots
-    const int slot = h->node_count;
-    int rc = lu_ensure_slots(h, slot + 1);
+    // Factor cache for one-off shifts (RCI jobs 10/11, linear_solver callbacks): a shift equal to
+    // a local quadrature node uses that node's slot, so an RCI sweep over the contour keeps one
+    // factorisation per node across refinement loops, as the reference's drivers do
+    // (factor_cache, src/dense/feast_dense.jl:458, 487-497); any other shift shares one extra slot.
+    int slot = h->node_count;
+    for (int e = 0; e < h->node_count && e < (int)h->node_ids.size(); ++e) {
+        const cplx ze = h->zne[h->node_ids[e]];
+        if (ze.x == z.x && ze.y == z.y) { slot = e; break; }
+    }
+    int rc = lu_ensure_slots(h, std::max(slot, h->node_count) + 1);
     if (rc) return rc;
     std::vector<int> need(1, slot), info;
     std::vector<cplx> zl(1, z);

@@ -651,6 +651,129 @@ def feast_general(A, B, Emid, r, M0, ne=16, fpm3=12, fpm4=20, fpm16=0, fpm18=100
 
 
 # ---------------------------------------------------------------------------
+# RCI kernels, jobs served exactly -- src/kernel/feast_kernel.jl:7-275 (srci), :397-644 (hrci)
+# (the general kernel grci, :646-962, is feast_general above)
+# ---------------------------------------------------------------------------
+def _ggev_scaled(S, A_):
+    """eigen(S, A) as LAPACK ggev leaves it (Julia does not rescale): each eigenvector has
+    max_i |re v_i| + |im v_i| = 1.  scipy normalises to unit 2-norm, which is undone here; the
+    srci/hrci residuals are taken on un-normalised Ritz vectors and depend on this."""
+    w, V = sla.eig(S, A_)
+    V = np.array(V, dtype=np.complex128)
+    for j in range(V.shape[1]):
+        s = np.max(np.abs(V[:, j].real) + np.abs(V[:, j].imag))
+        if s > 0:
+            V[:, j] = V[:, j] / s
+    return w, V
+
+
+def rci_symmetric(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, Q0=None, seed=20260515, contour=None,
+                  rhs_uses_B=True):
+    """What feast_srci! returns when its FACTORIZE/SOLVE/MULT_A jobs are served with exact dense
+    solves (caller loops: src/banded/feast_banded.jl:87-175 -- rhs = B*work; matrix-free
+    src/interfaces/feast_matfree.jl:203-254 -- rhs = work, ``rhs_uses_B=False``).
+    Moments in complex, real part after the sweep (:146-169); reduced pencil eigen(Sq, Aq) (:175);
+    q = Re(Q_proj) V with no normalisation (:183-187); inside-first stable reorder (:189-215);
+    residual ||A q - lambda q|| / max(|lambda|,1) WITHOUT B (:244-252); stop test uses loop >=
+    fpm[4] (:258); all M0 Ritz vectors are the next trial subspace (:269)."""
+    A = np.asarray(A.todense() if _is_sparse(A) else A, dtype=np.float64)
+    N = A.shape[0]
+    Bd = np.eye(N) if B is None else np.asarray(B.todense() if _is_sparse(B) else B, dtype=np.float64)
+    Zne, Wne = contour if contour is not None else feast_contour(Emin, Emax, ne)
+    if Q0 is None:
+        Q = np.real(seeded_subspace(N, M0, seed))
+    else:
+        Q = np.array(Q0, dtype=np.float64)
+        Q = Q / np.linalg.norm(Q, axis=0)
+    eps_tol = feast_tolerance(fpm3)
+    loop = 0
+    while True:
+        Qp = np.zeros((N, M0), dtype=np.complex128)
+        zA = np.zeros((M0, M0), dtype=np.complex128)
+        zS = np.zeros((M0, M0), dtype=np.complex128)
+        for e in range(len(Zne)):
+            Y = np.linalg.solve(Zne[e] * Bd - A, (Bd @ Q if rhs_uses_B else Q).astype(np.complex128))
+            wt = 2 * Wne[e]
+            Qp += wt * Y
+            mom = Q.T @ Y
+            zA += wt * mom
+            zS += Zne[e] * (wt * mom)
+        try:
+            w, V = _ggev_scaled(zS.real, zA.real)
+        except Exception:
+            return FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), FEAST_ERROR_LAPACK, 0.0, loop)
+        lam = np.real(w)
+        X = Qp.real @ np.real(V)
+        ins = [i for i in range(M0) if Emin <= lam[i] <= Emax]
+        perm = ins + [i for i in range(M0) if not (Emin <= lam[i] <= Emax)]
+        M = len(ins)
+        lam, X = lam[perm], X[:, perm]
+        if M == 0:
+            return FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), FEAST_ERROR_NO_CONVERGENCE, 0.0, loop)
+        res = np.zeros(M0)
+        AX = A @ X[:, :M]
+        for j in range(M):
+            res[j] = np.linalg.norm(AX[:, j] - lam[j] * X[:, j]) / max(abs(lam[j]), 1.0)
+        epsout = float(res[:M].max())
+        if epsout <= eps_tol or loop >= fpm4:
+            lam, X, res = feast_sort(lam, X, res, M)
+            return FeastResult(lam[:M].copy(), X[:, :M].copy(), M, res[:M].copy(), FEAST_SUCCESS, epsout, loop)
+        loop += 1
+        Q = X.copy()
+
+
+def rci_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, Q0=None, seed=20260515, contour=None):
+    """What feast_hrci! returns with exact solves (feast_kernel.jl:397-644): complex trial
+    subspace, zAq/zSq accumulated in place WITHOUT a per-sweep reset other than the one at the
+    start of a refinement loop (:618-619), reduced pencil eigen(zSq, zAq) in complex (:539),
+    q = Q_proj V complex (:547), lambda = real parts (:540)."""
+    A = np.asarray(A.todense() if _is_sparse(A) else A, dtype=np.complex128)
+    N = A.shape[0]
+    Bd = np.eye(N, dtype=np.complex128) if B is None else np.asarray(B.todense() if _is_sparse(B) else B, dtype=np.complex128)
+    Zne, Wne = contour if contour is not None else feast_contour(Emin, Emax, ne)
+    if Q0 is None:
+        Q = seeded_subspace(N, M0, seed, complex_values=True)
+    else:
+        Q = np.array(Q0, dtype=np.complex128)
+        Q = Q / np.linalg.norm(Q, axis=0)
+    eps_tol = feast_tolerance(fpm3)
+    loop = 0
+    while True:
+        Qp = np.zeros((N, M0), dtype=np.complex128)
+        zA = np.zeros((M0, M0), dtype=np.complex128)
+        zS = np.zeros((M0, M0), dtype=np.complex128)
+        for e in range(len(Zne)):
+            Y = np.linalg.solve(Zne[e] * Bd - A, Bd @ Q)
+            wt = 2 * Wne[e]
+            Qp += wt * Y
+            temp = Q.conj().T @ Y
+            zA += wt * temp
+            zS += wt * Zne[e] * temp
+        try:
+            w, V = _ggev_scaled(zS, zA)
+        except Exception:
+            return FeastResult(np.zeros(0), np.zeros((N, 0), complex), 0, np.zeros(0), FEAST_ERROR_LAPACK, 0.0, loop)
+        lam = np.real(w)
+        X = Qp @ V
+        ins = [i for i in range(M0) if Emin <= lam[i] <= Emax]
+        perm = ins + [i for i in range(M0) if not (Emin <= lam[i] <= Emax)]
+        M = len(ins)
+        lam, X = lam[perm], X[:, perm]
+        if M == 0:
+            return FeastResult(np.zeros(0), np.zeros((N, 0), complex), 0, np.zeros(0), FEAST_ERROR_NO_CONVERGENCE, 0.0, loop)
+        res = np.zeros(M0)
+        AX = A @ X[:, :M]
+        for j in range(M):
+            res[j] = np.linalg.norm(AX[:, j] - lam[j] * X[:, j]) / max(abs(lam[j]), 1.0)
+        epsout = float(res[:M].max())
+        if epsout <= eps_tol or loop >= fpm4:
+            lam, X, res = feast_sort(lam, X, res, M)
+            return FeastResult(lam[:M].copy(), X[:, :M].copy(), M, res[:M].copy(), FEAST_SUCCESS, epsout, loop)
+        loop += 1
+        Q = X.copy()
+
+
+# ---------------------------------------------------------------------------
 # Synthetic BASELINE inputs with closed-form spectra (SURVEY.md section 8d)
 # ---------------------------------------------------------------------------
 def laplacian_3d(nx, ny, nz):
