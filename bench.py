@@ -154,7 +154,9 @@ def main():
     # work per launch; the average launch time from HIP events on the launch stream (1 launch in 8).
     N, nnz = A.shape[0], A.nnz
     upd_cls = "cocg_xr" if args.solver == "cocg" else "bicg_xr"
-    upd_passes = 6 if args.solver == "cocg" else 7
+    # COCG runs in sum mode inside contour_apply: the update kernel reads R, Q and writes R (3 passes);
+    # the solution panels are replaced by one shared accumulator handled in k_cocg_p_sum
+    upd_passes = 3 if args.solver == "cocg" else 7
     pmc = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
@@ -206,6 +208,8 @@ def main():
         "eigenpairs": int(res.M), "expected_eigenpairs": int(len(inside)), "max_residual": max_res,
         "max_eigenvalue_error": eig_err, "loops": int(res.loop), "converged": bool(ok),
         "krylov_iterations_per_step": int(res.stats.get("krylov_iterations", 0)),
+        "phase_seconds_last_step": {k: round(v, 4) for k, v in res.stats.get("phase_seconds", {}).items()},
+        "solve_seconds_last_step": round(float(res.stats.get("solve_seconds", 0.0)), 4),
         "roofline": roofline, "roofline_other": roofline_other, "kernel_classes": classes,
         "mixed_precision": {"value": round(mixed.M / mixed_elapsed, 3) if mixed.info == 0 else 0.0, "unit": "eigenpairs/s",
                             "note": "same solve with complex64 Krylov correction panels (not the headline value)",

@@ -101,6 +101,7 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     if (!h) return FEASTHIP_ERROR_MEMORY;
     h->device = device_id;
     if (getenv("FH_LU_KB")) h->lu_outer_block = std::max(32, (atoi(getenv("FH_LU_KB")) / 32) * 32);
+    h->sum_mode = getenv("FH_NO_SUM_MODE") ? 0 : 1;
     h->lu_panel_legacy = getenv("FH_LU_PANEL_LEGACY") ? atoi(getenv("FH_LU_PANEL_LEGACY")) : 0;
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
@@ -473,9 +474,14 @@ struct fh_solve_result {
     double max_rel_res = 0.0;
 };
 
+// sum_acc != null (COCG only): "sum mode" -- X keeps the initial guess, every step alpha p of every
+// node is added, weighted with wnode[e], to the N x ld accumulator sum_acc (zeroed by the caller), so
+// that  sum_e w_e X_e(final) = sum_e w_e X_e(initial) + sum_acc.
 static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int nodes, const std::vector<cplx>& z,
-                     const cplx* RHS, cplx* X, size_t stride, fh_solve_result& res) {
+                     const cplx* RHS, cplx* X, size_t stride, fh_solve_result& res, cplx* sum_acc = nullptr,
+                     const std::vector<cplx>* wnode = nullptr) {
     if (h->kind != 2) prec = 64;          // the dense operator kernel takes complex128 panels only
+    if (method != 1 || !wnode) sum_acc = nullptr;
     const int N = (int)fh_N(h);
     const size_t panel = (size_t)N * ld;
     if (stride != panel) { h->last_error = "internal: solution stride mismatch"; return FEASTHIP_ERROR_INTERNAL; }
@@ -496,9 +502,15 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     s.r0norm = (double*)p; s.target = s.r0norm + nl; s.rnorm = s.target + nl;
     double* r0_64 = s.rnorm + nl;            // fp64 initial-residual norms (mixed precision)
     double* inv_r0 = r0_64 + nl;
-    if ((rc = fh_get_buf(h, "kry_scal_i", (3 * nl + nodes + 4) * sizeof(int), &p))) return rc;
+    if ((rc = fh_get_buf(h, "kry_scal_i", (4 * nl + 2 * nodes + 4) * sizeof(int), &p))) return rc;
     s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
     int* d_count = s.node_active + nodes;
+    cplx* d_wnode = nullptr;
+    if (sum_acc) {
+        s.accum = d_count + 4; s.node_accum = s.accum + nl;
+        FH_CHECK(hipMemsetAsync(s.accum, 0, (nl + nodes) * sizeof(int), h->stream));
+        if ((rc = fh_upload_coefs(h, "kry_wnode", *wnode, &d_wnode))) return rc;
+    }
     const int nblk_op = fh_op_nblk(h, ld);
     const int nblk_vec = fh_kry_nblk(N, ld, nodes);
     const int nblk_max = std::max(nblk_op, nblk_vec);
@@ -525,6 +537,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     va.N = N; va.node_stride = panel; va.R = R; va.Rhat = Rh; va.P = P; va.V = V; va.S = S; va.T = T;
     va.s = s; va.partial1 = part1; va.partial2 = part2; va.prec = prec;
     va.counters = h->profiling ? h->d_counters : nullptr;
+    va.sum_acc = sum_acc; va.wnode = d_wnode; va.sum_scale = (sum_acc && prec == 32) ? r0_64 : nullptr; va.nodes = nodes;
 
     void* Xk = X;        // the panel the Krylov recurrences update
     if (prec == 64) {
@@ -625,7 +638,10 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                 fh_prof_begin(h, "cocg_xr"); fh_launch_cocg_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
                 fa.nblk = nblk_vec;
                 fh_prof_begin(h, "dot_finalize"); fh_launch_fin_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
-                fh_prof_begin(h, "cocg_p"); fh_launch_cocg_p(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "cocg_p");
+                if (sum_acc) fh_launch_cocg_p_sum(va, ld, nodes, h->stream);
+                else fh_launch_cocg_p(va, ld, nblk_vec, nodes, h->stream);
+                fh_prof_end(h);
                 res.op_calls += 1;
             }
         }
@@ -645,7 +661,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     if (getenv("FH_DEBUG_TIMING"))
         fprintf(stderr, "[fh_krylov] nodes=%d its queued=%d loop wall %.3f ms\n", nodes, it,
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count());
-    if (prec == 32)    // X = X0 + ||r0|| d
+    if (prec == 32 && !sum_acc)    // X = X0 + ||r0|| d
         fh_launch_widen_axpy(X, panel, (const cplxf*)Xk, panel, r0_64, N, ld, nblk_vec, nodes, h->stream);
 
     // gather per-column bookkeeping
@@ -889,6 +905,7 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     if ((rc = fh_get_buf(h, "ca_Y", (size_t)nodes * panel * sizeof(cplx), &p))) return rc;
     cplx* Y = (cplx*)p;
     std::vector<int> status(nodes, 0);
+    cplx* sum_acc = nullptr;
 
     hipEvent_t ev0, ev1;
     FH_CHECK(hipEventCreate(&ev0)); FH_CHECK(hipEventCreate(&ev1));
@@ -920,7 +937,14 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
         va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz;
         fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
         fh_solve_result sr;
-        rc = fh_krylov(h, h->solver == FEASTHIP_SOLVER_COCG ? 1 : 0, h->factor_precision, ld, m, nodes, z, Rhs, Y, panel, sr);
+        // sum mode: only Q_proj is wanted (no moments), so the per-node solutions are never formed
+        if (h->solver == FEASTHIP_SOLVER_COCG && !dzAq && !dzSq && h->sum_mode) {
+            if ((rc = fh_get_buf(h, "ca_acc", panel * sizeof(cplx), &p))) return rc;
+            sum_acc = (cplx*)p;
+            FH_CHECK(hipMemsetAsync(sum_acc, 0, panel * sizeof(cplx), h->stream));
+        }
+        rc = fh_krylov(h, h->solver == FEASTHIP_SOLVER_COCG ? 1 : 0, h->factor_precision, ld, m, nodes, z, Rhs, Y, panel, sr,
+                       sum_acc, &w);
         if (rc) return rc;
         status = sr.status;
         h->last_node_iters = sr.node_iters;
@@ -966,7 +990,7 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     cplx* dw;
     if ((rc = fh_upload_coefs(h, "ca_w", w, &dw))) return rc;
     fh_prof_begin(h, "accumulate");
-    fh_launch_accumulate(Y, panel, dw, nodes, N, ld, Outp, h->real_projection, h->stream);
+    fh_launch_accumulate(Y, panel, dw, nodes, N, ld, sum_acc, Outp, h->real_projection, h->stream);
     fh_prof_end(h);
     fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream);
 

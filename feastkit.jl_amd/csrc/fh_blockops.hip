@@ -62,23 +62,24 @@ void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int6
 }
 
 // ---------------------------------------------------------------------------------------
-// dst = sum_e w[e] X[e]   (fixed summation order => bitwise reproducible)
+// dst = [extra +] sum_e w[e] X[e]   (fixed summation order => bitwise reproducible)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FH_BLOCK) void k_accumulate(const cplx* __restrict__ X, size_t node_stride,
                                                           const cplx* __restrict__ w, int nodes, size_t total,
-                                                          cplx* __restrict__ dst, int real_part) {
+                                                          cplx* __restrict__ dst, int real_part,
+                                                          const cplx* __restrict__ extra) {
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-        cplx acc = cmake(0, 0);
+        cplx acc = extra ? extra[e] : cmake(0, 0);
         for (int n = 0; n < nodes; ++n) cfma(acc, w[n], X[(size_t)n * node_stride + e]);
         if (real_part) acc.y = 0.0;
         dst[e] = acc;
     }
 }
-void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld,
+void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld, const cplx* extra,
                           cplx* dst, int real_part, hipStream_t st) {
     size_t total = (size_t)N * ld;
     int nblk = (int)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048);
-    hipLaunchKernelGGL(k_accumulate, dim3(nblk), dim3(FH_BLOCK), 0, st, X, node_stride, w, nodes, total, dst, real_part);
+    hipLaunchKernelGGL(k_accumulate, dim3(nblk), dim3(FH_BLOCK), 0, st, X, node_stride, w, nodes, total, dst, real_part, extra);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -108,6 +108,8 @@ struct fh_krylov_scalars {
     int* iters = nullptr;     // iterations performed by the column
     int* status = nullptr;    // 0 converged, 5 not converged, 8 breakdown
     int* node_active = nullptr;  // [nodes]: number of active columns of the node
+    int* accum = nullptr;        // sum mode: column took an alpha step in this iteration (set by fin_alpha)
+    int* node_accum = nullptr;   // [nodes]: any column of the node did
 };
 
 struct feasthip_ctx {
@@ -145,6 +147,7 @@ struct feasthip_ctx {
     std::vector<int*> lu_pivots;
     std::vector<int> lu_valid;
     std::vector<cplx> lu_z;
+    int sum_mode = 1;             // COCG contour_apply accumulates alpha*p into one shared panel (FH_NO_SUM_MODE=1 disables)
     int lu_outer_block = 128;     // FH_LU_KB: outer block column of the two-level LU (multiple of 32)
     int lu_panel_legacy = 0;      // FH_LU_PANEL_LEGACY=1: per-column global-memory panel kernel
 

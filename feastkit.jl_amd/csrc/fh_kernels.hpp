@@ -36,6 +36,12 @@ struct fh_vec_args {
     cplx* partial1; cplx* partial2;
     int prec;                  // 64 | 32
     unsigned long long* counters;   // measurement: [2] += active columns of this launch (update kernels), may be null
+    // sum mode (COCG inside contour_apply): the per-node solutions are never formed; every step
+    // alpha p of every node goes straight into the shared accumulator  ACC += w_node alpha [scale] p
+    cplx* sum_acc;             // N x LD fp64 accumulator, or null (solutions are updated in X)
+    const cplx* wnode;         // [nodes] quadrature weights
+    const double* sum_scale;   // [nodes x LD] column scale of the correction (mixed precision) or null
+    int nodes;
 };
 struct fh_fin_args {
     fh_krylov_scalars s;
@@ -53,6 +59,7 @@ void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipS
 void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+void fh_launch_cocg_p_sum(const fh_vec_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
@@ -73,7 +80,7 @@ void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int6
 // real column-major source -> complex panel
 void fh_launch_to_panel_real(const double* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
 // dst = sum_e w[e] * X[e]
-void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld,
+void fh_launch_accumulate(const cplx* X, size_t node_stride, const cplx* w, int nodes, int N, int ld, const cplx* extra,
                           cplx* dst, int real_part, hipStream_t st);
 // G (ld x ld, column-major, ldg = ld) = X^H Y (bilinear=0) or X^T Y (bilinear=1); f64 MFMA.
 // work: at least fh_gram_work_elems(ld) cplx.

@@ -472,20 +472,31 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_alpha(fh_fin_args a) {
     // alpha = rho / sigma   (sigma = <rhat, v> for BiCGStab, p^T S p for COCG)
     __shared__ cplx red[FH_FIN_BLOCK];
     const int node = blockIdx.x, t = threadIdx.x;
-    if (a.s.node_active[node] == 0) return;
+    if (a.s.node_active[node] == 0) {
+        if (a.s.accum) {
+            if (t < LD) a.s.accum[node * LD + t] = 0;
+            if (t == 0) a.s.node_accum[node] = 0;
+        }
+        return;
+    }
     cplx sigma = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
     if (t < LD) {
         const int i = node * LD + t;
+        int stepped = 0;
         if (a.s.active[i]) {
             cplx al = cdiv(a.s.rho[i], sigma);
             if (cabs2(sigma) == 0.0 || !fh_finite(al)) {
                 a.s.active[i] = 0;
                 a.s.status[i] = 8;   // breakdown
                 al = cmake(0, 0);
+            } else {
+                stepped = 1;
             }
             a.s.alpha[i] = al;
         }
+        if (a.s.accum) a.s.accum[i] = stepped;
     }
+    if (t == 0 && a.s.accum) a.s.node_accum[node] = 1;
 }
 
 template <int LD>
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_init(fh_vec_args a) {
 template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
     // X += alpha P ; R -= alpha Q (Q stored in V) ; partial1 = sum R*R, partial2 = sum |R|^2
+    // sum mode: X is not touched here (k_cocg_p_sum adds alpha P to the shared accumulator): 3 passes
     const int node = blockIdx.y;
     const int c = threadIdx.x % LD;
     if (a.counters && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.counters + 2, (unsigned long long)a.s.node_active[node]);
@@ -608,19 +620,29 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
     if (on) {
         const size_t total = (size_t)a.N * LD;
         const CT alpha = cvt<CT>(a.s.alpha[node * LD + c]);
-        const CT* P = (const CT*)a.P + (size_t)node * a.node_stride;
         const CT* Q = (const CT*)a.V + (size_t)node * a.node_stride;
-        CT* X = (CT*)a.X + (size_t)node * a.node_stride;
         CT* R = (CT*)a.R + (size_t)node * a.node_stride;
-        for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
-            CT x = X[e];
-            cfma(x, alpha, P[e]);
-            X[e] = x;
-            CT r = csub(R[e], cmul(alpha, Q[e]));
-            R[e] = r;
-            const cplx rd = to_d(r);
-            d1 = cadd(d1, cmul(rd, rd));
-            d2.x += cabs2(rd);
+        if (a.sum_acc) {
+            for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+                CT r = csub(R[e], cmul(alpha, Q[e]));
+                R[e] = r;
+                const cplx rd = to_d(r);
+                d1 = cadd(d1, cmul(rd, rd));
+                d2.x += cabs2(rd);
+            }
+        } else {
+            const CT* P = (const CT*)a.P + (size_t)node * a.node_stride;
+            CT* X = (CT*)a.X + (size_t)node * a.node_stride;
+            for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+                CT x = X[e];
+                cfma(x, alpha, P[e]);
+                X[e] = x;
+                CT r = csub(R[e], cmul(alpha, Q[e]));
+                R[e] = r;
+                const cplx rd = to_d(r);
+                d1 = cadd(d1, cmul(rd, rd));
+                d2.x += cabs2(rd);
+            }
         }
     }
     __shared__ cplx red[FH_BLOCK];
@@ -641,6 +663,53 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_p(fh_vec_args a) {
     CT* P = (CT*)a.P + (size_t)node * a.node_stride;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK)
         P[e] = cadd(R[e], cmul(beta, P[e]));
+}
+
+// Sum mode: P = R + beta P for every node AND  ACC += sum_nodes w_node alpha [scale] P_old  in one
+// pass.  contour_apply only needs Q_proj = sum_e w_e Y_e, never Y_e itself, so the solution panels
+// (one read + one write per node and iteration in k_cocg_update) are replaced by one shared
+// accumulator (one read + one write per iteration for ALL nodes).  Nodes are summed in index
+// order by the thread that owns the element: deterministic, no atomics.  A column that converged
+// in this iteration is no longer `active` but still has `accum` set (fin_alpha): its last step is
+// accumulated, its P is left alone.
+#define FH_PSUM_K 4
+template <typename CT, int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_p_sum(fh_vec_args a) {
+    const size_t total = (size_t)a.N * LD;
+    const size_t e0 = (size_t)blockIdx.x * FH_PSUM_K * FH_BLOCK + threadIdx.x;
+    const int c = threadIdx.x % LD;
+    cplx acc[FH_PSUM_K];
+#pragma unroll
+    for (int k = 0; k < FH_PSUM_K; ++k) acc[k] = cmake(0, 0);
+    bool any = false;
+    for (int n = 0; n < a.nodes; ++n) {
+        if (!a.s.node_accum[n]) continue;                       // uniform over the grid
+        const int i = n * LD + c;
+        if (!a.s.accum[i]) continue;
+        any = true;
+        const bool act = a.s.active[i] != 0;
+        cplx coef = cmul(a.wnode[n], a.s.alpha[i]);
+        if (a.sum_scale) { const double sc = a.sum_scale[i]; coef.x *= sc; coef.y *= sc; }
+        const CT beta = cvt<CT>(a.s.beta[i]);
+        const CT* R = (const CT*)a.R + (size_t)n * a.node_stride;
+        CT* P = (CT*)a.P + (size_t)n * a.node_stride;
+#pragma unroll
+        for (int k = 0; k < FH_PSUM_K; ++k) {
+            const size_t e = e0 + (size_t)k * FH_BLOCK;
+            if (e < total) {
+                const CT p = P[e];
+                cfma(acc[k], coef, to_d(p));
+                if (act) P[e] = cadd(R[e], cmul(beta, p));
+            }
+        }
+    }
+    if (any) {
+#pragma unroll
+        for (int k = 0; k < FH_PSUM_K; ++k) {
+            const size_t e = e0 + (size_t)k * FH_BLOCK;
+            if (e < total) a.sum_acc[e] = cadd(a.sum_acc[e], acc[k]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -689,6 +758,12 @@ void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hi
 }
 void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
     FH_DISPATCH_VEC(a.prec, ld, k_cocg_p, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_p_sum(const fh_vec_args& a, int ld, int nodes, hipStream_t st) {
+    (void)nodes;
+    const size_t total = (size_t)a.N * ld;
+    const int nblk = (int)((total + (size_t)FH_PSUM_K * FH_BLOCK - 1) / ((size_t)FH_PSUM_K * FH_BLOCK));
+    FH_DISPATCH_VEC(a.prec, ld, k_cocg_p_sum, dim3(nblk), st, a);
 }
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st) {
     FH_DISPATCH_FIN(ld, k_fin_init, dim3(nodes), st, a);

@@ -11,7 +11,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 A, B, lam = fk.workloads.laplacian_3d_pencil(50, 40, 25)
 eng = fk.HipEngine(0)
 eng.set_problem(A, B)
-Z, W = fk.feast_contour(0.0, 0.1775, 16)
+fpm = fk.feastdefault(fk.feastinit()); fpm[2] = 16
+Z, W = fk.feast_contour(0.0, 0.1775, fpm)
 eng.set_contour(Z, W, 2.0)
 eng.set_node_range(0, nodes)
 eng.set_solver(os.environ.get("SOLVER","bicgstab"), rtol=0.0, atol=0.0, maxit=maxit, factor_precision=int(os.environ.get("PREC","64")))
