@@ -7,6 +7,8 @@ per-quadrature-node operation.
         _feast_sparse_hermitian         src/sparse/feast_sparse.jl:246-499
   feast_hip_general    -- variant C maths of feast_grci!/feast_gegv!
         src/kernel/feast_kernel.jl:646-962, src/dense/feast_dense.jl:402-593
+  feast_hip_complex_symmetric -- complex-symmetric sibling of variant A (q^T instead of q^H)
+        src/dense/feast_dense.jl:1026-1259, src/sparse/feast_sparse.jl:509-711
 
 Quadrature nodes are block-partitioned over the ranks of a ``torch.distributed`` process
 group exactly like ``distribute_contour_points`` (src/parallel/feast_parallel.jl:433-447);
@@ -353,6 +355,113 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
             return FeastResult(lam[:M][order].copy(), X[:, :M][:, order].copy(), M, res[order].copy(), 0, epsout, loop, stats)
         loop += 1
         dQ = dX
+
+
+def feast_hip_complex_symmetric(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver_tol=0.0,
+                                solver_maxiter=500, solver_restart=30, group=None, Q0=None, seed=20260515):
+    """Complex-symmetric sibling of variant A (A == A^T, B == B^T, complex): the loop of
+    _feast_dense_complex_symmetric / its sparse twin (src/dense/feast_dense.jl:1026-1259,
+    src/sparse/feast_sparse.jl:509-711).  Same kernels as the Hermitian path with the full
+    contour (weights unscaled), pivoted-QR compression, the BILINEAR projection q^T A q, q^T B q
+    (feasthip_project bilinear=1), general reduced eigenproblem on the host, inside-first
+    reorder by the contour, all rank columns normalised, residual with B, sort by |lambda|^2.
+    Sparse input may use solver="cocg": z B - A is complex symmetric for complex-symmetric A, B
+    -- the COCG kernels need real A, B, so complex input goes through "bicgstab"/"gmres"."""
+    import scipy.sparse as _sp
+    N = A.shape[0]
+    feastdefault(fpm)
+    empty = lambda code, loop=0: FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), code, math.inf, loop)
+    if N <= 0:
+        return empty(1)
+    if M0 <= 0 or M0 > N:
+        return empty(2)
+    if not r > 0:
+        return empty(4)
+    if M0 > 64:
+        raise ValueError("the :hip backend currently takes M0 <= 64 per call (FH_MAX_LD)")
+    for name, Mx in (("A", A), ("B", B)):
+        if Mx is None:
+            continue
+        sym = (abs(Mx - Mx.T).max() == 0) if _sp.issparse(Mx) else np.array_equal(Mx, Mx.T)
+        if not sym:                                          # check_complex_symmetric, feast_dense.jl:1038
+            raise ValueError(f"Matrix {name} must be complex symmetric ({name} == transpose({name}))")
+    rank_, world = _world(group)
+    iterative = solver not in ("direct", "lu")
+    tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
+    Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
+    Bc = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B) else B)
+    engine.set_problem(Ac, Bc)
+    Zne, Wne = feast_gcontour(Emid, r, fpm)
+    engine.set_contour(Zne, Wne, 1.0)
+    engine.set_real_projection(False)
+    first, count = distribute_contour_points(len(Zne), world)[rank_]
+    engine.set_node_range(first, count)
+    engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
+                      restart=solver_restart, cache_factors=True)
+    dQ = engine.upload(seeded_subspace(N, M0, seed, complex_values=True) if Q0 is None else np.asarray(Q0, dtype=np.complex128))
+    eps_tol = feast_tolerance(fpm)
+    maxloop = int(fpm[4])
+    info, epsout, M_found, active, loop_count = 0, math.inf, 0, M0, 0
+    lam_vec = np.zeros(M0, dtype=np.complex128)
+    res_vec = np.zeros(M0)
+    dX = None
+    stats = {"krylov_iterations": 0, "factorizations": 0, "solve_seconds": 0.0}
+    for loop_idx in range(0, maxloop + 1):
+        loop_count = loop_idx
+        dP, status, st = engine.contour_apply(dQ, active, None)
+        stats["krylov_iterations"] += st.get("krylov_iterations", 0)
+        stats["factorizations"] += st.get("factorizations", 0)
+        stats["solve_seconds"] += st.get("seconds_solve", 0.0)
+        fail = int(np.max(status[:max(count, 1)])) if count > 0 else 0
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([float(fail)], dtype=torch.float64, device=dP.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            fail = int(flag.item())
+            engine.allreduce_sum(dP, group)
+        if fail:
+            info = int(FeastError.Feast_ERROR_LAPACK if fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        rank_q = engine.orthonormalize(dP, active, SQRT_EPS)                  # _feast_qr_compress!, :1163
+        if rank_q == 0:
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        Ared, Bred = engine.project(dP, rank_q, bilinear=True, hermitize=False)   # q^T A q, q^T B q
+        try:
+            lam_red, v_red = sla.eig(Ared, Bred)
+        except Exception:
+            info = int(FeastError.Feast_ERROR_LAPACK)
+            break
+        ins = [i for i in range(rank_q) if feast_inside_gcontour(lam_red[i], Emid, r, fpm)]
+        M = len(ins)
+        if M == 0:
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        inset = set(ins)
+        perm = np.array(ins + [i for i in range(rank_q) if i not in inset], dtype=np.int64)
+        lam_sorted = lam_red[perm]
+        V = np.asfortranarray(v_red[:, perm])
+        dX, res = engine.ritz_residual(dP, rank_q, V, lam_sorted, rank_q, normalize=True, use_B=True)
+        lam_vec[:rank_q] = lam_sorted
+        res_vec[:M] = res[:M]
+        epsout = float(res[:M].max())
+        M_found = M
+        if epsout <= eps_tol:
+            break
+        if loop_idx == maxloop:
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        active = rank_q
+        dQ = dX
+    if M_found == 0 and info == 0:
+        info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+    if dX is None or M_found == 0:
+        return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), info, epsout, loop_count, stats)
+    X = engine.download(dX, M_found)
+    order = sorted(range(M_found), key=lambda i: abs(lam_vec[i]) ** 2)         # feast_sort_general!
+    return FeastResult(lam_vec[:M_found][order].copy(), X[:, order].copy(), M_found, res_vec[:M_found][order].copy(),
+                       info, epsout, loop_count, stats)
 
 
 def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None, seed=20260515):

@@ -651,6 +651,82 @@ def feast_general(A, B, Emid, r, M0, ne=16, fpm3=12, fpm4=20, fpm16=0, fpm18=100
 
 
 # ---------------------------------------------------------------------------
+# Complex-symmetric sibling of variant A -- src/dense/feast_dense.jl:1026-1259,
+# src/sparse/feast_sparse.jl:509-711
+# ---------------------------------------------------------------------------
+def feast_complex_symmetric(A, B, Emid, r, M0, ne=16, fpm3=12, fpm4=20, fpm16=0, fpm18=100, fpm19=0,
+                            Q0=None, seed=20260515):
+    """Full contour, no factor 2 (:1107), pivoted-QR compression (:1163), BILINEAR projection
+    Ared = q^T A q, Bred = q^T B q (:1181-1182), eigen(Ared, Bred) (:1184), inside-first reorder by
+    the contour (:1193), ALL rank columns normalised (:1200-1209), residual WITH B (:1211-1224),
+    final sort by |lambda|^2 (:1250)."""
+    A = np.asarray(A.todense() if _is_sparse(A) else A, dtype=np.complex128)
+    N = A.shape[0]
+    if not np.array_equal(A, A.T):
+        raise ValueError("Matrix A must be complex symmetric (A == transpose(A))")
+    Bd = None if B is None else np.asarray(B.todense() if _is_sparse(B) else B, dtype=np.complex128)
+    if Bd is not None and not np.array_equal(Bd, Bd.T):
+        raise ValueError("Matrix B must be complex symmetric (B == transpose(B))")
+    Zne, Wne = feast_gcontour(Emid, r, ne, fpm16, fpm18, fpm19)
+    Q = seeded_subspace(N, M0, seed, complex_values=True) if Q0 is None else np.array(Q0, dtype=np.complex128)
+    eps_tol = feast_tolerance(fpm3)
+    factors = {}
+    lam = np.zeros(M0, dtype=np.complex128)
+    X = np.zeros((N, M0), dtype=np.complex128)
+    res = np.zeros(M0)
+    info, epsout, M_found, active, loop_count = FEAST_SUCCESS, math.inf, 0, M0, 0
+    for loop in range(0, fpm4 + 1):
+        loop_count = loop
+        Qp = np.zeros((N, active), dtype=np.complex128)
+        rhs = Q[:, :active] if Bd is None else Bd @ Q[:, :active]
+        for e, z in enumerate(Zne):
+            if e not in factors:
+                factors[e] = sla.lu_factor(dense_shifted_identity_minus(z, A) if Bd is None else z * Bd - A)
+            Qp += Wne[e] * sla.lu_solve(factors[e], rhs)
+        q, rank = qr_compress(Qp, active)
+        if rank == 0:
+            info = FEAST_ERROR_NO_CONVERGENCE
+            break
+        Ared = q.T @ (A @ q)
+        Bred = q.T @ (q if Bd is None else Bd @ q)
+        try:
+            lam_red, v_red = sla.eig(Ared, Bred)
+        except Exception:
+            info = FEAST_ERROR_LAPACK
+            break
+        Xr = q @ v_red
+        ins = [i for i in range(rank) if inside_gcontour(lam_red[i], Emid, r, fpm18, fpm19)]
+        perm = ins + [i for i in range(rank) if i not in set(ins)]
+        M = len(ins)
+        if M == 0:
+            info = FEAST_ERROR_NO_CONVERGENCE
+            break
+        lam[:rank] = lam_red[perm]
+        Xr = Xr[:, perm]
+        nrm = np.linalg.norm(Xr, axis=0)
+        nrm[nrm == 0] = 1.0
+        Xr = Xr / nrm
+        X[:, :rank] = Xr
+        for j in range(M):
+            xj = Xr[:, j]
+            res[j] = np.linalg.norm(A @ xj - lam[j] * (xj if Bd is None else Bd @ xj)) / max(abs(lam[j]), 1.0)
+        epsout = float(res[:M].max())
+        M_found = M
+        if epsout <= eps_tol:
+            break
+        if loop == fpm4:
+            info = FEAST_ERROR_NO_CONVERGENCE
+            break
+        active = rank
+        Q = Xr.copy()
+    if M_found == 0 and info == FEAST_SUCCESS:
+        info = FEAST_ERROR_NO_CONVERGENCE
+    if M_found > 1:
+        lam, X, res = feast_sort_general(lam, X, res, M_found)
+    return FeastResult(lam[:M_found].copy(), X[:, :M_found].copy(), M_found, res[:M_found].copy(), info, epsout, loop_count)
+
+
+# ---------------------------------------------------------------------------
 # RCI kernels, jobs served exactly -- src/kernel/feast_kernel.jl:7-275 (srci), :397-644 (hrci)
 # (the general kernel grci, :646-962, is feast_general above)
 # ---------------------------------------------------------------------------

@@ -325,3 +325,59 @@ def test_variant_b_moments_on_gpu(engine):
                               *k["interval"], 4, ne=k["fpm2"], fpm4=k["fpm4"])
         assert r.info == 0 == o.info and r.M == 3 == o.M
         assert np.allclose(r.lambda_, k["expect_lambda"], atol=k["atol"]) and np.allclose(r.lambda_, o.lam, atol=1e-9)
+
+
+# ---- complex-symmetric sibling of variant A (src/dense/feast_dense.jl:1026-1259, feast_sparse.jl:509-711)
+def _complex_symmetric_problem(n, seed=7, generalized=False):
+    rng = np.random.default_rng(seed)
+    d = np.linspace(-2.0, 2.0, n) + 1j * rng.uniform(-0.6, 0.6, n)
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))          # real orthogonal: A = Qo D Qo^T is complex symmetric
+    A = Qo @ np.diag(d) @ Qo.T
+    A = 0.5 * (A + A.T)
+    B = None
+    if generalized:
+        B = Qo @ np.diag(1.0 + 0.3 * rng.random(n)) @ Qo.T
+        B = (0.5 * (B + B.T)).astype(complex)
+    return A, B, d
+
+
+@pytest.mark.parametrize("generalized", [False, True])
+def test_complex_symmetric_dense_matches_oracle(engine, generalized):
+    A, B, _ = _complex_symmetric_problem(48, generalized=generalized)
+    ev = np.linalg.eigvals(A if B is None else np.linalg.solve(B, A))
+    c = 0.2 + 0.05j
+    dist = np.sort(np.abs(ev - c))
+    r = 0.5 * (dist[7] + dist[8])
+    want = fo.feast_complex_symmetric(A, B, c, r, 12, ne=16, fpm3=11, fpm4=20)
+    fpm = fk.feastinit(); fpm[8] = 16; fpm[3] = 11; fpm[4] = 20
+    got = fk.feast_hip_complex_symmetric(engine, A, B, c, r, 12, fpm)
+    assert (got.info, got.M) == (want.info, want.M) == (0, 8)
+    assert abs(got.loop - want.loop) <= 1
+    inside = ev[np.abs(ev - c) <= r]
+    key = lambda x: (round(x.real, 6), round(x.imag, 6))
+    assert np.allclose(sorted(got.lambda_, key=key), sorted(inside, key=key), atol=1e-9)
+    assert np.allclose(sorted(got.lambda_, key=key), sorted(want.lam, key=key), atol=1e-9)
+    assert got.epsout <= 1e-11
+    X = got.q
+    Bm = np.eye(48) if B is None else B
+    assert np.linalg.norm(A @ X - (Bm @ X) * got.lambda_[None, :]) < 1e-9
+
+
+def test_complex_symmetric_sparse_bicgstab(engine):
+    """CSR complex-symmetric pencil: tridiagonal with complex diagonal (a cluster of 10 entries near 2.7,
+    the rest in [4.5, 8]), Krylov solves on the device."""
+    n = 300
+    rng = np.random.default_rng(2)
+    diag = np.linspace(4.5, 8.0, n) + 0.3j * rng.uniform(-1, 1, n)
+    idx = np.arange(10) * 29 + 5
+    diag[idx] = 2.7 + 0.15 * rng.uniform(-1, 1, 10) + 0.1j * rng.uniform(-1, 1, 10)
+    A = sp.diags([-0.2 * np.ones(n - 1), diag, -0.2 * np.ones(n - 1)], [-1, 0, 1], format="csr").astype(complex)
+    ev = np.linalg.eigvals(A.toarray())
+    c, r = 2.7 + 0.0j, 0.9
+    inside = ev[np.abs(ev - c) <= r]
+    fpm = fk.feastinit(); fpm[8] = 16; fpm[3] = 10; fpm[4] = 25
+    got = fk.feast_hip_complex_symmetric(engine, A, None, c, r, 16, fpm, solver="bicgstab", solver_tol=1e-12, solver_maxiter=3000)
+    assert got.info == 0 and got.M == len(inside) == 10
+    key = lambda x: (round(x.real, 6), round(x.imag, 6))
+    assert np.allclose(sorted(got.lambda_, key=key), sorted(inside, key=key), atol=1e-8)
+    assert got.epsout <= 1e-10

@@ -228,3 +228,45 @@ def test_variant_b_moments_loop_equals_oracle():
         got = fk.pfeast_hip_moments(OracleEngine(), Ain, Bin, *k["interval"], 4, fpm, Q0=Q0.copy())
         assert (got.info, got.M, got.loop) == (ref.info, ref.M, ref.loop) == (0, 3, ref.loop)
         assert np.allclose(got.lambda_, ref.lam, atol=1e-12) and np.allclose(got.lambda_, k["expect_lambda"], atol=k["atol"])
+
+
+# ---- complex-symmetric sibling (src/dense/feast_dense.jl:1026-1259) ---------------------------------
+def _complex_symmetric_problem(n=24, seed=7, generalized=False):
+    rng = np.random.default_rng(seed)
+    d = np.linspace(-2.0, 2.0, n) + 1j * rng.uniform(-0.6, 0.6, n)
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))          # real orthogonal: Qo^T = Qo^-1
+    A = Qo @ np.diag(d) @ Qo.T + 0.0 * G
+    A = 0.5 * (A + A.T)
+    B = None
+    if generalized:
+        B = Qo @ np.diag(1.0 + 0.3 * rng.random(n)) @ Qo.T
+        B = (0.5 * (B + B.T)).astype(complex)
+    return A, B
+
+
+@pytest.mark.parametrize("generalized", [False, True])
+def test_complex_symmetric_matches_oracle(generalized):
+    A, B = _complex_symmetric_problem(generalized=generalized)
+    ev = np.linalg.eigvals(A if B is None else np.linalg.solve(B, A))
+    c = 0.2 + 0.05j
+    dist = np.sort(np.abs(ev - c))
+    r = 0.5 * (dist[5] + dist[6])
+    want = fo.feast_complex_symmetric(A, B, c, r, 10, ne=16, fpm3=10, fpm4=20)
+    fpm = fk.feastinit(); fpm[8] = 16; fpm[3] = 10; fpm[4] = 20
+    got = fk.feast_hip_complex_symmetric(OracleEngine(), A, B, c, r, 10, fpm)
+    assert (got.info, got.M) == (want.info, want.M) == (0, 6)
+    assert abs(got.loop - want.loop) <= 1
+    inside = ev[np.abs(ev - c) <= r]
+    key = lambda x: (round(x.real, 6), round(x.imag, 6))
+    assert np.allclose(sorted(got.lambda_, key=key), sorted(inside, key=key), atol=1e-8)
+    assert np.allclose(sorted(got.lambda_, key=key), sorted(want.lam, key=key), atol=1e-9)
+    assert got.epsout <= 1e-10
+
+
+def test_complex_symmetric_rejects_nonsymmetric():
+    A = np.array([[1.0, 2.0], [0.0, 3.0]], dtype=complex)
+    with pytest.raises(ValueError):
+        fk.feast_hip_complex_symmetric(OracleEngine(), A, None, 0j, 1.0, 2, fk.feastinit())
+    with pytest.raises(ValueError):
+        fo.feast_complex_symmetric(A, None, 0j, 1.0, 2)
