@@ -17,6 +17,7 @@ from .hip_backend import (feast_hip_hermitian, feast_hip_general, feast_hip_comp
 from .engine import HipEngine   # noqa: F401
 from .api import feast, feast_general   # noqa: F401
 from . import rci   # noqa: F401
+from . import ingest   # noqa: F401
 from .rci import (RciRefs, RciState, HipRciServer, feast_srci, feast_hrci, feast_grci,   # noqa: F401
                   rci_solve_symmetric, rci_solve_hermitian, rci_solve_general)
 

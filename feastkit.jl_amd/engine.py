@@ -109,6 +109,24 @@ class HipEngine:
                                             nb, _np_ptr(pb), _np_ptr(ib), _np_ptr(vb)))
         self.N, self.b_identity = N, B is None
 
+    def set_problem_csc(self, N, A_csc, B_csc=None, index_base=1):
+        """Raw ``SparseMatrixCSC`` arrays (colptr, rowval, nzval) as the Julia shim passes them
+        (set_matrices!): storage = CSC, 1-based by default; transposed on ingest."""
+        pa, ia, va = A_csc
+        cplx = np.iscomplexobj(va) or (B_csc is not None and np.iscomplexobj(B_csc[2]))
+        dt = np.complex128 if cplx else np.float64
+        pa, ia, va = np.ascontiguousarray(pa, dtype=np.int64), np.ascontiguousarray(ia, dtype=np.int64), np.ascontiguousarray(va, dtype=dt)
+        if B_csc is not None:
+            pb, ib, vb = (np.ascontiguousarray(B_csc[0], dtype=np.int64), np.ascontiguousarray(B_csc[1], dtype=np.int64),
+                          np.ascontiguousarray(B_csc[2], dtype=dt))
+            nb = len(vb)
+        else:
+            pb = ib = vb = None
+            nb = 0
+        self._chk(self.lib.feasthip_set_csr(self.h, int(N), int(cplx), int(index_base), 1, len(va), _np_ptr(pa), _np_ptr(ia), _np_ptr(va),
+                                            nb, _np_ptr(pb), _np_ptr(ib), _np_ptr(vb)))
+        self.N, self.b_identity = int(N), B_csc is None
+
     def set_contour(self, Zne, Wne, weight_scale):
         z = np.ascontiguousarray(Zne, dtype=np.complex128)
         w = np.ascontiguousarray(Wne, dtype=np.complex128)

@@ -1,0 +1,94 @@
+"""Matrix ingest (feastkit.jl_amd/ingest.py): the compact MatrixMarket-like readers of
+examples/feast/utils.jl:15-170 and the Julia-CSC array view."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import feastkit_jl_amd as fk
+from feastkit_jl_amd import ingest
+
+
+def test_dense_reader_last_duplicate_wins_sparse_reader_sums(tmp_path):
+    p = tmp_path / "m.mtx"
+    p.write_text("3 3 5\n1 1 2.0\n2 3 -1.5\n3 2 4.0\n1 1 7.0\n2 3 0.5\n")
+    D = ingest.read_mm_dense_real(str(p))
+    assert D.shape == (3, 3) and D[0, 0] == 7.0 and D[1, 2] == 0.5 and D[2, 1] == 4.0
+    S = ingest.read_mm_sparse_real(str(p))
+    assert sp.isspmatrix_csc(S) and S[0, 0] == 9.0 and S[1, 2] == -1.0 and S.nnz == 3
+
+
+def test_complex_readers_and_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    A = sp.random(20, 20, density=0.2, random_state=1, format="coo") + 1j * sp.random(20, 20, density=0.2, random_state=2, format="coo")
+    p = tmp_path / "c.mtx"
+    ingest.write_mm(str(p), A)
+    S = ingest.read_mm_sparse_complex(str(p))
+    assert abs(S - sp.csc_matrix(A)).max() == 0
+    D = ingest.read_mm_dense_complex(str(p))
+    assert np.array_equal(D, A.toarray())
+    R = sp.random(15, 15, density=0.3, random_state=3)
+    ingest.write_mm(str(p), R)
+    assert abs(ingest.read_mm_sparse_real(str(p)) - sp.csc_matrix(R)).max() == 0
+
+
+def test_banded_reader_lapack_layout(tmp_path):
+    n = 7
+    A = np.zeros((n, n))
+    for i in range(n):
+        for j in range(max(0, i - 2), min(n, i + 2)):      # kl = 2, ku = 1
+            A[i, j] = 10 * (i + 1) + (j + 1)
+    p = tmp_path / "b.mtx"
+    ingest.write_mm(str(p), sp.coo_matrix(A))
+    band, kl, ku = ingest.read_banded_real(str(p))
+    assert (kl, ku) == (2, 1) and band.shape == (4, n)
+    for j in range(n):
+        for i in range(max(0, j - ku), min(n, j + kl + 1)):
+            assert band[ku + i - j, j] == A[i, j]            # AB(ku+1+i-j, j) = A(i,j), 1-based
+    assert np.array_equal(ingest.banded_to_dense(band, kl, ku), A)
+    Ac = A + 1j * np.tril(A, -1)
+    ingest.write_mm(str(p), sp.coo_matrix(Ac))
+    bc, kl, ku = ingest.read_banded_complex(str(p))
+    assert np.array_equal(ingest.banded_to_dense(bc, kl, ku), Ac)
+
+
+def test_reader_errors(tmp_path):
+    p = tmp_path / "bad.mtx"
+    p.write_text("2 2 2\n1 1 1.0\n")
+    with pytest.raises(ValueError):
+        ingest.read_mm_sparse_real(str(p))
+    p.write_text("2 2 1\n3 1 1.0\n")
+    with pytest.raises(ValueError):
+        ingest.read_mm_dense_real(str(p))
+
+
+def test_julia_csc_arrays():
+    A = sp.csc_matrix(np.array([[1.0, 0, 2], [0, 3, 0], [4, 0, 5]]))
+    colptr, rowval, nzval = ingest.julia_csc(A)
+    assert colptr.dtype == np.int64 and rowval.dtype == np.int64
+    assert colptr.tolist() == [1, 3, 4, 6] and rowval.tolist() == [1, 3, 2, 1, 3] and nzval.tolist() == [1.0, 4.0, 3.0, 2.0, 5.0]
+
+
+@pytest.mark.gpu
+def test_file_to_device_solve(engine, tmp_path):
+    """Fixture file -> reader -> Julia-CSC arrays -> feasthip_set_csr(CSC, base 1) -> eigenpairs.
+    Complex Hermitian input: reading the CSC arrays as CSR would hand over conj(A); the product
+    check below fails in that case."""
+    n = 60
+    rng = np.random.default_rng(4)
+    off = 0.3 * (rng.standard_normal(n - 1) + 1j * rng.standard_normal(n - 1))
+    A = sp.diags([off.conj(), np.linspace(1.0, 7.0, n), off], [-1, 0, 1], format="csc")
+    p = tmp_path / "h.mtx"
+    ingest.write_mm(str(p), A)
+    S = ingest.read_mm_sparse_complex(str(p))
+    engine.set_problem_csc(n, ingest.julia_csc(S))
+    X = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    Y = engine.download(engine.matmul(0, engine.upload(X), 3), 3)
+    assert np.allclose(Y, A @ X, atol=1e-13)
+    assert not np.allclose(Y, A.T @ X, atol=1e-6)
+    ev = np.linalg.eigvalsh(A.toarray())
+    lo, hi = 0.5 * (ev[9] + ev[10]), 0.5 * (ev[17] + ev[18])
+    # complex Hermitian input runs the reference's half-contour filter (contracts ~0.5 per loop): allow 60 loops
+    fpm = fk.feastinit(); fpm[2] = 8; fpm[3] = 10; fpm[4] = 60
+    r = fk.feast_hip_hermitian(engine, S, None, lo, hi, 12, fpm, solver="bicgstab", solver_tol=1e-13, solver_maxiter=4000,
+                               real_projection=False)
+    assert r.info == 0 and r.M == 8 and np.allclose(r.lambda_, ev[10:18], atol=1e-9)
