@@ -366,6 +366,14 @@ extern "C" int feasthip_set_node_list(feasthip_handle h, int count, const int* i
     return 0;
 }
 
+extern "C" int feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (m < 0 || m > FH_MAX_LD) { h->last_error = "set_column_mask: m out of range"; return FEASTHIP_ERROR_M0; }
+    h->col_mask.clear();
+    if (mask && m > 0) h->col_mask.assign(mask, mask + m);
+    return 0;
+}
+
 extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit, int restart,
                                    int factor_precision, int cache_factors) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
@@ -531,7 +539,15 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     oc.partial1 = part1; oc.partial2 = part2; oc.U = nullptr; oc.u_stride = 0;
     fh_fin_args fa;
     fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
-    fa.atol_scale = nullptr; fa.mode = method;
+    fa.atol_scale = nullptr; fa.mode = method; fa.col_mask = nullptr;
+    if (!h->col_mask.empty()) {
+        std::vector<int> mk(ld, 1);
+        for (int c = 0; c < ld && c < (int)h->col_mask.size(); ++c) mk[c] = h->col_mask[c];
+        if ((rc = fh_get_buf(h, "kry_colmask", ld * sizeof(int), &p))) return rc;
+        FH_CHECK(hipMemcpyAsync(p, mk.data(), ld * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        fa.col_mask = (const int*)p;
+    }
     fh_vec_args va;
     memset(&va, 0, sizeof(va));
     va.N = N; va.node_stride = panel; va.R = R; va.Rhat = Rh; va.P = P; va.V = V; va.S = S; va.T = T;
@@ -1176,12 +1192,34 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
             fh_prof_end(h);
             FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
             FH_CHECK(hipStreamSynchronize(h->stream));
+            std::vector<double> dcol;
             if (pass == 0) {
-                double ratio = fh_pivoted_cholesky_ratio(Gh, m, ld);
-                double thr = std::max(1e-10, rank_tol * rank_tol * 1e4);
-                if (!(ratio > thr)) { ok = false; break; }
+                // Equilibrate: G = D G' D with D = diag(column norms).  Columns of very different
+                // length (e.g. guard columns scaled by a small filter value) make G ill-conditioned
+                // although the directions are fine; Cholesky of G' is as stable as for unit columns.
+                // Full rank in the sense of the reference's pivoted-QR rule is accepted only with a
+                // wide margin: |R_kk|/|R_11| >~ (d_min/d_max) sqrt(ratio') must exceed 1e3 rank_tol.
+                dcol.resize(m);
+                double dmin = 0.0, dmax = 0.0;
+                for (int j = 0; j < m; ++j) {
+                    const double g = Gh[(size_t)j * ld + j].x;
+                    dcol[j] = g > 0.0 && std::isfinite(g) ? std::sqrt(g) : 0.0;
+                    dmin = j == 0 ? dcol[j] : std::min(dmin, dcol[j]);
+                    dmax = std::max(dmax, dcol[j]);
+                }
+                if (!(dmin > 0.0)) { ok = false; break; }
+                for (int j = 0; j < m; ++j)
+                    for (int i = 0; i < m; ++i) {
+                        cplx& g = Gh[(size_t)j * ld + i];
+                        g = cscale(g, 1.0 / (dcol[i] * dcol[j]));
+                    }
+                const double ratio = fh_pivoted_cholesky_ratio(Gh, m, ld);
+                if (!(ratio > 1e-10) || !((dmin / dmax) * std::sqrt(ratio) > 1e3 * rank_tol)) { ok = false; break; }
             }
             if (!fh_chol_upper_inverse(Gh, m, ld, Rinv)) { ok = false; break; }
+            if (pass == 0)       // R = R' D  =>  R^-1 = D^-1 R'^-1: scale row i by 1/d_i
+                for (int j = 0; j < m; ++j)
+                    for (int i = 0; i < m; ++i) Rinv[(size_t)j * ld + i] = cscale(Rinv[(size_t)j * ld + i], 1.0 / dcol[i]);
             FH_CHECK(hipMemcpyAsync(dR, Rinv.data(), Rinv.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
             fh_prof_begin(h, "ortho");
             fh_launch_small_matmul(src, dR, N, ld, dst, h->stream);

@@ -50,6 +50,7 @@ struct fh_fin_args {
     double rtol, atol;
     const double* atol_scale;  // per (node,column) factor on atol (mixed precision: 1/||r0||), may be null
     int mode;                  // 0 BiCGStab, 1 COCG
+    const int* col_mask;       // [LD] 0 = column keeps its initial guess and is never iterated; may be null
 };
 void fh_launch_init_guess(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_copy_r(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);

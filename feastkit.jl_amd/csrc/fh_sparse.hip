@@ -458,7 +458,7 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_init(fh_fin_args a) {
         a.s.omega[i] = cmake(1, 0);
         a.s.beta[i] = cmake(0, 0);
         a.s.iters[i] = 0;
-        int act = (t < a.m) && (rn > target) && isfinite(rn);
+        int act = (t < a.m) && (rn > target) && isfinite(rn) && (!a.col_mask || a.col_mask[t]);
         a.s.active[i] = act;
         a.s.status[i] = (t < a.m && !isfinite(rn)) ? 8 : 0;
         if (act) atomicAdd(&cnt, 1);

@@ -151,6 +151,15 @@ class HipEngine:
                                                int(restart), int(factor_precision), int(bool(cache_factors))))
 
     # -- device arrays (plumbing) -----------------------------------------------------
+    def set_column_mask(self, mask):
+        """mask[c] == 0: column c is not iterated by the Krylov solvers (keeps its warm start);
+        ``None`` clears the mask."""
+        if mask is None:
+            self._chk(self.lib.feasthip_set_column_mask(self.h, 0, None))
+            return
+        mk = np.ascontiguousarray(mask, dtype=np.int32)
+        self._chk(self.lib.feasthip_set_column_mask(self.h, len(mk), _np_ptr(mk)))
+
     def empty(self, m):
         return self.torch.empty((m, self.N), dtype=self.torch.complex128, device=self.device)
 

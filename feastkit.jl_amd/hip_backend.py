@@ -74,7 +74,7 @@ def _reduced_hermitian_eig(Sq, Aq):
         return np.real(w).astype(np.float64), V
 
 
-def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0,
+def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_after=None, solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
                         preloaded=False, node_assignment="block", inner_precision=64, column_groups=1):
@@ -197,6 +197,13 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         loop_count = loop_idx
         t_ = tick()
         lam_guess = ritz_lambda if (iterative and warm_start) else None
+        col_mask = None
+        if lam_guess is not None and freeze_guards_after is not None and loop_idx > freeze_guards_after:
+            # guard columns (Ritz value outside the interval) keep their warm start q/(z - lambda): they
+            # stay in the subspace, scaled by the filter value, but no solves are spent on them
+            col_mask = np.array([1 if Emin <= lam_guess[c] <= Emax else 0 for c in range(active)], dtype=np.int32)
+        if hasattr(engine, "set_column_mask"):
+            engine.set_column_mask(col_mask if column_groups == 1 else None)
         if column_groups == 1:
             dP, status, st = engine.contour_apply(dQ, active, lam_guess)
         else:
@@ -205,6 +212,8 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
             dP.zero_()
             status, st = np.zeros(max(1, count), dtype=np.int32), {}
             if c1 > c0:
+                if hasattr(engine, "set_column_mask"):
+                    engine.set_column_mask(None if col_mask is None else col_mask[c0:c1])
                 dPs, status, st = engine.contour_apply(dQ[c0:c1], c1 - c0, None if lam_guess is None else lam_guess[c0:c1])
                 dP[c0:c1] = dPs[:c1 - c0]
         ph["apply"] += tick() - t_
@@ -274,6 +283,8 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", s
         dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
         ritz_lambda = lam_sorted.copy()
 
+    if hasattr(engine, "set_column_mask"):
+        engine.set_column_mask(None)
     if M_found == 0 and info == 0:
         info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
     q = engine.download(dX, M_found) if (dX is not None and M_found > 0) else np.zeros((N, 0), dtype=np.complex128)

@@ -129,6 +129,13 @@ int  feasthip_set_node_range(feasthip_handle h, int first, int count);
  * summed result is independent of the assignment.                                       */
 int  feasthip_set_node_list(feasthip_handle h, int count, const int* indices);
 
+/* Inexact-FEAST extension (not in the reference): columns c < m with mask[c] == 0 keep their initial
+ * guess (the Ritz warm start q_c/(z - lambda_c) when ritz_lambda is given) and are never iterated by
+ * the Krylov solvers of the following contour_apply calls.  Used to stop spending solves on the
+ * guard columns (Ritz values outside the interval) once the subspace has settled.  mask == NULL or
+ * m == 0 clears it.  Ignored by the LU path.                                                */
+int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
+
 /* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
  * (src/dense/feast_dense.jl:81-84).  Iterative stop test is Krylov.jl's
  * ||r_k|| <= atol + rtol*||r_0|| per column.  factor_precision 64|32 (dense LU only;

@@ -129,3 +129,35 @@ def test_error_codes(raw):
     Q1 = np.asfortranarray(np.ones((4, 1), dtype=np.complex128))
     assert lib.feasthip_contour_apply(h, 1, _ptr(Q1), None, _ptr(P), None, None, _ptr(status), None) == 0
     assert status[0] == 8
+
+
+def test_column_mask_keeps_initial_guess(engine):
+    """feasthip_set_column_mask: masked columns come back as their initial guess summed over the
+    nodes -- sum_e w_e q_c / (z_e - lambda_c) with the Ritz warm start -- unmasked columns are solved."""
+    import feast_oracle as fo
+    import feastkit_jl_amd as fk
+    A, B, lam = fo.cfg3_problem(8, 7, 6)
+    N = A.shape[0]
+    engine.set_problem(A, B)
+    fpm = fk.feastdefault(fk.feastinit()); fpm[2] = 4
+    Z, W = fk.feast_contour(0.0, 0.9, fpm)
+    engine.set_contour(Z, W, 2.0)
+    engine.set_real_projection(False)
+    engine.set_solver("cocg", rtol=1e-12, atol=0.0, maxit=4000)
+    Q = fk.seeded_subspace(N, 4)
+    ritz = np.array([0.3, 0.5, 1.4, 2.0])
+    try:
+        engine.set_column_mask([1, 0, 1, 0])
+        dP, status, st = engine.contour_apply(engine.upload(Q), 4, ritz)
+    finally:
+        engine.set_column_mask(None)
+    P = engine.download(dP, 4)
+    Sd = [Z[e] * B.toarray() - A.toarray() for e in range(4)]
+    for c in range(4):
+        if c in (1, 3):
+            want = sum(2 * W[e] / (Z[e] - ritz[c]) for e in range(4)) * Q[:, c]
+        else:
+            want = sum(2 * W[e] * np.linalg.solve(Sd[e], B @ Q[:, c]) for e in range(4))
+        assert np.allclose(P[:, c], want, atol=1e-9), c
+    lib = engine.lib
+    assert lib.feasthip_set_column_mask(engine.h, 65, None) == 2

@@ -192,7 +192,11 @@ def test_cfg3_reduced_reference_mode_and_fast_mode(engine):
     assert ref.info == 0
     mixed = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm_with(f2=8, f4=40), engine=engine, solver="bicgstab",
                      warm_start=True, inner_rtol=1e-2, solver_maxiter=100, inner_precision=32)
-    for r in (strict, fast, mixed):
+    # guard columns (Ritz value outside the interval) keep their warm start after loop 2: same answer
+    fpm = fpm_with(f2=8, f4=40)
+    frozen = fk.feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, solver="cocg", warm_start=True, inner_rtol=1e-2,
+                                    solver_maxiter=100, real_projection=True, freeze_guards_after=2)
+    for r in (strict, fast, mixed, frozen):
         assert r.info == 0 and r.M == len(inside) == ref.M
         assert np.allclose(np.sort(r.lambda_), inside, atol=1e-10)
         assert np.allclose(np.sort(r.lambda_), np.sort(ref.lam), atol=1e-10)
