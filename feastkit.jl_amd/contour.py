@@ -11,6 +11,35 @@ def _gauss(n):
     return np.polynomial.legendre.leggauss(n)   # FastGaussQuadrature.gausslegendre(n)
 
 
+_ZOLOTAREV = None
+
+
+def zolotarev_point(n, k):
+    """Zolotarev node and weight k (1..n; k = 0: the constant term) on the unit disc --
+    src/core/feast_tools.jl:182-210.  The constants are FEAST's libnum tables, shipped as data
+    (zolotarev_tables.json, extracted by tests/golden/make_zolotarev_tables.py); for an n that
+    is not tabulated the reference warns and falls back to a trapezoid-like rule (:196-209)."""
+    global _ZOLOTAREV
+    if _ZOLOTAREV is None:
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "zolotarev_tables.json")) as f:
+            _ZOLOTAREV = json.load(f)
+    tab = _ZOLOTAREV.get(str(int(n)))
+    if tab is not None:
+        if k == 0:
+            return 0j, complex(*tab["we0"])
+        if 1 <= k <= len(tab["nodes"]):
+            xr, xi, wr, wi = tab["nodes"][k - 1]
+            return complex(xr, xi), complex(wr, wi)
+    import warnings
+    warnings.warn(f"Zolotarev quadrature not available for n={n}, using approximation")
+    if k == 0:
+        return 0j, 1 + 0j
+    theta = math.pi * (2 * k - 1) / (2 * n)
+    return complex(math.cos(theta), math.sin(theta)), complex(0.0, math.pi / n)
+
+
 def feast_contour(Emin, Emax, fpm):
     """Half contour for Hermitian problems: src/core/feast_tools.jl:212-284."""
     ne, fpm16, fpm18 = int(fpm[2]), int(fpm[16]), int(fpm[18])
@@ -21,9 +50,12 @@ def feast_contour(Emin, Emax, fpm):
     Wne = np.empty(ne, dtype=np.complex128)
     if fpm16 == 0:
         x, w = _gauss(ne)
-    elif fpm16 == 2:
-        raise NotImplementedError("Zolotarev quadrature (fpm[16]=2) is a table lookup kept on the Julia host")
     for e in range(ne):
+        if fpm16 == 2:                       # Zolotarev: nodes/weights scaled by r (:263-266)
+            zx, zw = zolotarev_point(ne, e + 1)
+            Zne[e] = zx * r + Emid
+            Wne[e] = zw * r
+            continue
         if fpm16 == 0:
             theta = -math.pi / 2 * x[e] + math.pi / 2
             fac = 0.25 * w[e]

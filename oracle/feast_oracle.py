@@ -73,8 +73,8 @@ def feast_contour(Emin, Emax, ne=8, fpm16=0, fpm18=100):
     """Half contour for Hermitian problems (src/core/feast_tools.jl:212-284).
 
     Returns (Zne, Wne) complex128 arrays of length ``ne``.
-    fpm16: 0 Gauss-Legendre, 1 trapezoid.  (2 = Zolotarev table is a data table
-    in the reference, not restated here.)
+    fpm16: 0 Gauss-Legendre, 1 trapezoid, 2 Zolotarev (constants of the reference's table
+    src/core/feast_tools.jl:50-180, read from the data file the package ships; :263-266).
     """
     r = (Emax - Emin) / 2.0
     Emid = Emin + r
@@ -95,8 +95,17 @@ def feast_contour(Emin, Emax, ne=8, fpm16=0, fpm18=100):
             Zne[e] = Emid + r * math.cos(theta) + 1j * r * aspect * math.sin(theta)
             jac = r * 1j * math.sin(theta) + r * aspect * math.cos(theta)
             Wne[e] = (1.0 / (2 * ne)) * jac
+    elif fpm16 == 2:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "feastkit.jl_amd", "zolotarev_tables.json")
+        tab = json.load(open(path))[str(ne)]
+        for e in range(ne):
+            xr, xi, wr, wi = tab["nodes"][e]
+            Zne[e] = complex(xr, xi) * r + Emid
+            Wne[e] = complex(wr, wi) * r
     else:
-        raise ValueError("fpm16 must be 0 (Gauss) or 1 (trapezoid) in the oracle")
+        raise ValueError("fpm16 must be 0 (Gauss), 1 (trapezoid) or 2 (Zolotarev)")
     return Zne, Wne
 
 

@@ -267,11 +267,11 @@ def test_contour_variants_trapezoid_and_ellipse(engine):
     N = 300
     A = fo.householder_conjugated_diag(0.02 * np.arange(N))
     want = 0.02 * np.arange(100, 108)
-    for kw in (dict(f16=1, f2=12), dict(f18=50, f2=8), dict(f16=1, f18=30, f2=16)):
+    for kw in (dict(f16=1, f2=12), dict(f18=50, f2=8), dict(f16=1, f18=30, f2=16), dict(f16=2, f2=8, f4=40)):   # f16=2: Zolotarev
         r = fk.feast(A, None, (1.99, 2.15), M0=20, fpm=fpm_with(**kw), engine=engine)
         assert r.info == 0 and r.M == 8 and np.allclose(np.sort(r.lambda_), want, atol=1e-10), kw
         o = fo.feast_hermitian(A, None, 1.99, 2.15, 20, ne=kw["f2"], fpm16=kw.get("f16", 0), fpm18=kw.get("f18", 100),
-                               real_projection=True)
+                               fpm4=kw.get("f4", 20), real_projection=True)
         assert o.info == 0 and np.allclose(np.sort(o.lam), want, atol=1e-10)
 
 

@@ -270,3 +270,42 @@ def test_complex_symmetric_rejects_nonsymmetric():
         fk.feast_hip_complex_symmetric(OracleEngine(), A, None, 0j, 1.0, 2, fk.feastinit())
     with pytest.raises(ValueError):
         fo.feast_complex_symmetric(A, None, 0j, 1.0, 2)
+
+
+# ---- Zolotarev quadrature (fpm[16] = 2), src/core/feast_tools.jl:50-210, 263-266 ---------------------
+def test_zolotarev_points_and_contour():
+    x, w = fk.zolotarev_point(1, 1)
+    assert x == 1j and abs(w - 0.99800399400799011j) < 1e-16            # table n = 1 (feast_tools.jl:51-53)
+    _, w0 = fk.zolotarev_point(1, 0)
+    assert abs(w0 + 0.49800399400799011) < 1e-16
+    x, w = fk.zolotarev_point(3, 2)
+    assert x == 1j and abs(w - 0.74467858236516826j) < 1e-16            # :60-63
+    with pytest.warns(UserWarning):                                       # n not tabulated -> fallback rule (:196-209)
+        x, w = fk.zolotarev_point(9, 1)
+    assert abs(x - np.exp(1j * np.pi / 18)) < 1e-15 and abs(w - 1j * np.pi / 9) < 1e-15
+    fpm = fk.feastdefault(fk.feastinit())
+    fpm[2], fpm[16] = 8, 2
+    Z, W = fk.feast_contour(1.0, 3.0, fpm)
+    Zo, Wo = fo.feast_contour(1.0, 3.0, 8, fpm16=2)
+    assert np.array_equal(Z, Zo) and np.array_equal(W, Wo)
+    for e in range(8):
+        x, w = fk.zolotarev_point(8, e + 1)
+        assert Z[e] == x * 1.0 + 2.0 and W[e] == w * 1.0
+    assert np.all(Z.imag > 0)                                             # upper half plane, symmetric pairs
+    assert np.allclose(np.sort(Z.real - 2.0), -np.sort(Z.real - 2.0)[::-1])
+    # the rational filter rho(lambda) = Re sum 2 w_e/(z_e - lambda) + we0 is ~1 inside, ~0 outside
+    _, w0 = fk.zolotarev_point(8, 0)
+    rho = lambda lam: float(np.real(np.sum(2 * W / (Z - lam))) + w0.real)
+    assert abs(rho(2.0) - 1.0) < 0.05 and abs(rho(2.6) - 1.0) < 0.05
+    assert abs(rho(5.0)) < 0.05 and abs(rho(-1.0)) < 0.05
+
+
+def test_zolotarev_hermitian_solve_matches_oracle():
+    A = tridiag(40)
+    ev = 2 - 2 * np.cos(np.arange(1, 41) * np.pi / 41)
+    lo, hi = 0.5 * (ev[7] + ev[8]), 0.5 * (ev[15] + ev[16])
+    fpm = fk.feastinit(); fpm[2] = 8; fpm[16] = 2; fpm[4] = 40
+    got = fk.feast_hip_hermitian(OracleEngine(), A, None, lo, hi, 12, fpm, real_projection=True)
+    want = fo.feast_hermitian(A, None, lo, hi, 12, ne=8, fpm16=2, fpm4=40, real_projection=True)
+    assert (got.info, got.M) == (want.info, want.M) == (0, 8)
+    assert np.allclose(got.lambda_, ev[8:16], atol=1e-10) and np.allclose(got.lambda_, want.lam, atol=1e-10)
