@@ -368,7 +368,7 @@ extern "C" int feasthip_set_node_list(feasthip_handle h, int count, const int* i
 
 extern "C" int feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
-    if (m < 0 || m > FH_MAX_LD) { h->last_error = "set_column_mask: m out of range"; return FEASTHIP_ERROR_M0; }
+    if (m < 0 || m > (1 << 20)) { h->last_error = "set_column_mask: m out of range"; return FEASTHIP_ERROR_M0; }
     h->col_mask.clear();
     if (mask && m > 0) h->col_mask.assign(mask, mask + m);
     return 0;
@@ -441,11 +441,12 @@ static int fh_op_nblk(feasthip_ctx* h, int ld) {
 static int64_t fh_N(feasthip_ctx* h) { return h->kind == 2 ? h->csr.N : h->dense.N; }
 static bool fh_b_identity(feasthip_ctx* h) { return h->kind == 2 ? h->csr.b_identity != 0 : h->dense.b_identity != 0; }
 
-static int fh_check_problem(feasthip_ctx* h, int64_t m) {
+// wide = 1: the entry point also takes m > FH_MAX_LD (processed in 64-column panels)
+static int fh_check_problem(feasthip_ctx* h, int64_t m, int wide = 0) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     if (h->kind == 0) { h->last_error = "no matrix set (feasthip_set_dense / feasthip_set_csr)"; return FEASTHIP_ERROR_N; }
-    if (m <= 0 || m > FH_MAX_LD || m > fh_N(h)) {
-        h->last_error = "block width m must satisfy 1 <= m <= min(N, 64)";
+    if (m <= 0 || (!wide && m > FH_MAX_LD) || m > fh_N(h)) {
+        h->last_error = wide ? "block width m must satisfy 1 <= m <= N" : "block width m must satisfy 1 <= m <= min(N, 64)";
         return FEASTHIP_ERROR_M0;
     }
     return 0;
@@ -872,8 +873,8 @@ static bool fh_is_complex_input(feasthip_ctx* h) { return h->kind == 2 ? h->csr.
 // ---------------------------------------------------------------------------------------
 // contour sweep
 // ---------------------------------------------------------------------------------------
-static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
-                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
+                                  cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
     int rc = fh_check_problem(h, m64);
     if (rc) return rc;
     if (h->zne.empty()) { h->last_error = "no contour set"; return FEASTHIP_ERROR_FPM; }
@@ -1048,6 +1049,46 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     return 0;
 }
 
+// m > 64: the columns of Q are independent right-hand sides, so the sweep runs panel by panel
+// (64 columns each); LU factors are shared by the panels through the per-node cache.
+static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
+                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+    if (m64 <= FH_MAX_LD) return fh_contour_apply_panel(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
+    int rc = fh_check_problem(h, m64, 1);
+    if (rc) return rc;
+    if (dzAq || dzSq) { h->last_error = "contour_apply: moment matrices need m <= 64"; return FEASTHIP_ERROR_M0; }
+    const int m = (int)m64, N = (int)fh_N(h), nodes = h->node_count;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    std::vector<int> ns(std::max(nodes, 1), 0), node_it(nodes, 0), col_it((size_t)nodes * m, 0);
+    if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = 0;
+    const std::vector<int> mask = h->col_mask;
+    for (int c0 = 0; c0 < m; c0 += FH_MAX_LD) {
+        const int mc = std::min(FH_MAX_LD, m - c0);
+        feasthip_stats st;
+        h->col_mask.clear();
+        if (!mask.empty()) for (int c = c0; c < c0 + mc; ++c) h->col_mask.push_back(c < (int)mask.size() ? mask[c] : 1);
+        h->last_node_iters.clear(); h->last_col_iters.clear();
+        rc = fh_contour_apply_panel(h, mc, dQ + (size_t)c0 * N, ritz_lambda ? ritz_lambda + c0 : nullptr,
+                                    dQproj + (size_t)c0 * N, nullptr, nullptr, ns.data(), &st);
+        h->col_mask = mask;
+        if (rc) return rc;
+        for (int e = 0; e < nodes; ++e) {
+            if (node_status) node_status[e] = std::max(node_status[e], ns[e]);
+            if (e < (int)h->last_node_iters.size()) node_it[e] = std::max(node_it[e], h->last_node_iters[e]);
+            for (int c = 0; c < mc; ++c)
+                if ((size_t)e * mc + c < h->last_col_iters.size()) col_it[(size_t)e * m + c0 + c] = h->last_col_iters[(size_t)e * mc + c];
+        }
+        if (stats) {
+            stats->seconds_total += st.seconds_total; stats->seconds_solve += st.seconds_solve;
+            stats->krylov_iterations += st.krylov_iterations; stats->spmm_calls += st.spmm_calls;
+            stats->factorizations += st.factorizations;
+            stats->max_rel_residual = std::max(stats->max_rel_residual, st.max_rel_residual);
+        }
+    }
+    h->last_node_iters = node_it; h->last_col_iters = col_it; h->last_col_m = m;
+    return 0;
+}
+
 extern "C" int feasthip_contour_apply_dev(feasthip_handle h, int64_t m, const void* dQ, const double* ritz_lambda_host,
                                           void* dQproj, void* dzAq, void* dzSq, int* node_status, feasthip_stats* stats) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
@@ -1065,7 +1106,7 @@ static int fh_stage_in(feasthip_ctx* h, const char* name, const void* host, size
 
 extern "C" int feasthip_contour_apply(feasthip_handle h, int64_t m, const void* Q, const double* ritz_lambda,
                                       void* Qproj, void* zAq, void* zSq, int* node_status, feasthip_stats* stats) {
-    int rc = fh_check_problem(h, m);
+    int rc = fh_check_problem(h, m, 1);
     if (rc) return rc;
     if (!Q || !Qproj) { h->last_error = "contour_apply: null Q/Qproj"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));
@@ -1150,18 +1191,14 @@ static bool fh_chol_upper_inverse(const std::vector<cplx>& G, int m, int ld, std
 // ---------------------------------------------------------------------------------------
 // orthonormalisation (a9)
 // ---------------------------------------------------------------------------------------
-extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void* dQ, double rank_tol, int* rank) {
-    int rc = fh_check_problem(h, m64);
-    if (rc) return rc;
-    if (!dQ || !rank) { h->last_error = "orthonormalize: null argument"; return FEASTHIP_ERROR_INTERNAL; }
-    FH_CHECK(hipSetDevice(h->device));
-    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
-    const size_t panel = (size_t)N * ld;
+// Rank-revealing orthonormalisation of the m (<= ld) columns of panel X.  On success *res is the
+// panel (X or Out) whose first *rank columns hold the basis.  ref_scale > 0 / big_dim: X is a
+// block of a wider matrix (see k_mgs_pick).
+static int fh_ortho_panel(feasthip_ctx* h, int m, int ld, cplx* X, cplx* Out, double rank_tol, double ref_scale,
+                          int big_dim, int* rank, cplx** res) {
+    const int N = (int)fh_N(h);
+    int rc;
     void* p;
-    if ((rc = fh_get_buf(h, "or_X", panel * sizeof(cplx), &p))) return rc;
-    cplx* X = (cplx*)p;
-    if ((rc = fh_get_buf(h, "or_out", panel * sizeof(cplx), &p))) return rc;
-    cplx* Out = (cplx*)p;
     if ((rc = fh_get_buf(h, "or_work", (size_t)256 * ld * sizeof(cplx), &p))) return rc;
     cplx* work = (cplx*)p;
     if ((rc = fh_get_buf(h, "or_istate", (4 + FH_MAX_LD) * sizeof(int), &p))) return rc;
@@ -1170,7 +1207,6 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
     double* dstate = (double*)p;
     if ((rc = fh_get_buf(h, "or_coef", FH_MAX_LD * sizeof(cplx), &p))) return rc;
     cplx* coef = (cplx*)p;
-    fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
     // Fast path (Cholesky-QR twice) when the panel is far from rank deficient: the pivoted
     // Cholesky pivots of the Gram matrix are the squared R_kk of the pivoted QR, so a pivot
     // ratio above 1e-10 means every |R_kk|/|R_11| > 1e-5 >> rank_tol and the reference rule
@@ -1200,7 +1236,7 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
                 // Full rank in the sense of the reference's pivoted-QR rule is accepted only with a
                 // wide margin: |R_kk|/|R_11| >~ (d_min/d_max) sqrt(ratio') must exceed 1e3 rank_tol.
                 dcol.resize(m);
-                double dmin = 0.0, dmax = 0.0;
+                double dmin = 0.0, dmax = ref_scale;
                 for (int j = 0; j < m; ++j) {
                     const double g = Gh[(size_t)j * ld + j].x;
                     dcol[j] = g > 0.0 && std::isfinite(g) ? std::sqrt(g) : 0.0;
@@ -1227,21 +1263,17 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
             FH_CHECK(hipStreamSynchronize(h->stream));     // Rinv (host vector) is reused
             std::swap(src, dst);
         }
-        if (ok) {
-            // two passes: the result is back in X (src after two swaps)
+        if (ok) {       // two passes: the result is back in X (src after two swaps)
             *rank = m;
-            fh_launch_from_panel(src, ld, N, m, (cplx*)dQ, N, h->stream);
-            FH_CHECK(hipStreamSynchronize(h->stream));
-            fh_prof_collect(h);
+            *res = src;
             return 0;
         }
-        // pass 0 failed before touching X; a failure in pass 1 leaves the first-pass result in
-        // `Out`, so re-read the input panel for the rank-revealing path
-        fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
+        // a failure happens before the pass writes its destination: X still holds the input
+        // (pass 0 writes Out, pass 1 would have written X)
     }
     fh_mgs_args a;
     a.X = X; a.N = N; a.ld = ld; a.m = m; a.istate = istate; a.dstate = dstate; a.coef = coef; a.work = work;
-    a.rank_tol = rank_tol;
+    a.rank_tol = rank_tol; a.ref_scale = ref_scale; a.big_dim = big_dim;
     fh_prof_begin(h, "ortho");
     fh_mgs_run(a, h->stream);
     fh_prof_end(h);
@@ -1253,14 +1285,107 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
     if (r > m) r = m;
     *rank = r;
     fh_launch_gather_cols(X, istate + 4, r, N, ld, Out, h->stream);
-    fh_launch_from_panel(Out, ld, N, m, (cplx*)dQ, N, h->stream);
+    *res = Out;
+    return 0;
+}
+
+// m > 64: block Gram-Schmidt over 64-column panels.  Panel j is projected twice against the kept
+// columns (C = K^H X_j on the MFMA Gram kernel, X_j -= K C), then orthonormalised by fh_ortho_panel
+// with the rank threshold tied to the largest column norm of the WHOLE matrix -- the R_11 of the
+// reference's pivoted QR (src/core/feast_aux.jl:113-124).  Kept columns are packed to the front of
+// Q.  Pivoting is per panel, not global: for a full-rank input the basis spans the same space.
+static int fh_ortho_wide(feasthip_ctx* h, int m, cplx* dQ, double rank_tol, int* rank) {
+    const int N = (int)fh_N(h), ld = FH_MAX_LD;
+    const size_t panel = (size_t)N * ld;
+    int rc;
+    void* p;
+    if ((rc = fh_get_buf(h, "or_X", panel * sizeof(cplx), &p))) return rc;
+    cplx* X = (cplx*)p;
+    if ((rc = fh_get_buf(h, "or_out", panel * sizeof(cplx), &p))) return rc;
+    cplx* Out = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ow_K", panel * sizeof(cplx), &p))) return rc;
+    cplx* K = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ow_T", panel * sizeof(cplx), &p))) return rc;
+    cplx* T = (cplx*)p;
+    if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
+    cplx* gw = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ow_C", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* C = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ow_part", (size_t)fh_vec_nblk(N, ld) * ld * sizeof(cplx), &p))) return rc;
+    cplx* part = (cplx*)p;
+    if ((rc = fh_get_buf(h, "ow_dots", (size_t)ld * sizeof(cplx), &p))) return rc;
+    cplx* ddots = (cplx*)p;
+    std::vector<cplx> ones(ld, cmake(1, 0));
+    cplx* done;
+    if ((rc = fh_upload_coefs(h, "ow_one", ones, &done))) return rc;
+    const int npan = (m + ld - 1) / ld;
+    // largest column norm of the whole matrix
+    double ref = 0.0;
+    std::vector<cplx> dots(ld);
+    for (int j = 0; j < npan; ++j) {
+        const int mj = std::min(ld, m - j * ld);
+        fh_launch_to_panel(dQ + (size_t)j * ld * N, N, N, mj, X, ld, h->stream);
+        fh_launch_dot_cols(X, X, N, ld, part, ddots, h->stream);
+        FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        for (int c = 0; c < mj; ++c) if (dots[c].x > ref * ref) ref = std::sqrt(dots[c].x);
+    }
+    int kept = 0;
+    for (int j = 0; j < npan; ++j) {
+        const int mj = std::min(ld, m - j * ld);
+        fh_launch_to_panel(dQ + (size_t)j * ld * N, N, N, mj, X, ld, h->stream);
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int k0 = 0; k0 < kept; k0 += ld) {
+                const int kw = std::min(ld, kept - k0);
+                fh_launch_to_panel(dQ + (size_t)k0 * N, N, N, kw, K, ld, h->stream);
+                fh_prof_begin(h, "gram");
+                fh_launch_gram(K, X, N, ld, 0, gw, C, h->stream);        // C = K^H X
+                fh_prof_end(h);
+                fh_prof_begin(h, "ortho");
+                fh_launch_small_matmul(K, C, N, ld, T, h->stream);       // T = K C
+                fh_launch_axpy_cols(X, T, done, N, ld, h->stream);       // X -= T
+                fh_prof_end(h);
+            }
+        }
+        int rj = 0;
+        cplx* res = nullptr;
+        if ((rc = fh_ortho_panel(h, mj, ld, X, Out, rank_tol, ref, m, &rj, &res))) return rc;
+        if (rj > 0) fh_launch_from_panel(res, ld, N, rj, dQ + (size_t)kept * N, N, h->stream);
+        kept += rj;
+    }
+    *rank = kept;
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void* dQ, double rank_tol, int* rank) {
+    int rc = fh_check_problem(h, m64, 1);
+    if (rc) return rc;
+    if (!dQ || !rank) { h->last_error = "orthonormalize: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    if (m64 > FH_MAX_LD) {
+        rc = fh_ortho_wide(h, (int)m64, (cplx*)dQ, rank_tol, rank);
+        fh_prof_collect(h);
+        return rc;
+    }
+    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    const size_t panel = (size_t)N * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "or_X", panel * sizeof(cplx), &p))) return rc;
+    cplx* X = (cplx*)p;
+    if ((rc = fh_get_buf(h, "or_out", panel * sizeof(cplx), &p))) return rc;
+    cplx* Out = (cplx*)p;
+    fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
+    cplx* res = nullptr;
+    if ((rc = fh_ortho_panel(h, m, ld, X, Out, rank_tol, 0.0, m, rank, &res))) return rc;
+    fh_launch_from_panel(res, ld, N, m, (cplx*)dQ, N, h->stream);
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
     return 0;
 }
 
 extern "C" int feasthip_orthonormalize(feasthip_handle h, int64_t m, void* Q, double rank_tol, int* rank) {
-    int rc = fh_check_problem(h, m);
+    int rc = fh_check_problem(h, m, 1);
     if (rc) return rc;
     if (!Q || !rank) { h->last_error = "orthonormalize: null argument"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));
@@ -1289,6 +1414,70 @@ static void fh_hermitize(std::vector<cplx>& G, int r) {
 
 extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* dQ, int bilinear, int hermitize,
                                     void* Aq_host, void* Bq_host) {
+    if (r64 > FH_MAX_LD) {
+        // r > 64: 64-column panels; block (i, j) of Q^H A Q is Q_i^H (A Q_j) on the MFMA Gram kernel
+        int rc0 = fh_check_problem(h, r64, 1);
+        if (rc0) return rc0;
+        if (!dQ || !Aq_host) { h->last_error = "project: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+        FH_CHECK(hipSetDevice(h->device));
+        const int r = (int)r64, ld = FH_MAX_LD, N = (int)fh_N(h);
+        const size_t panel = (size_t)N * ld;
+        void* p;
+        int rc;
+        if ((rc = fh_get_buf(h, "pj_Q", panel * sizeof(cplx), &p))) return rc;
+        cplx* Qi = (cplx*)p;
+        if ((rc = fh_get_buf(h, "pj_Qj", panel * sizeof(cplx), &p))) return rc;
+        cplx* Qj = (cplx*)p;
+        if ((rc = fh_get_buf(h, "pj_W", panel * sizeof(cplx), &p))) return rc;
+        cplx* W = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
+        cplx* gw = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gram_G", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+        cplx* G = (cplx*)p;
+        std::vector<cplx> one(ld, cmake(1, 0)), zero(ld, cmake(0, 0));
+        cplx *d1, *d0;
+        if ((rc = fh_upload_coefs(h, "pj_one", one, &d1))) return rc;
+        if ((rc = fh_upload_coefs(h, "pj_zero", zero, &d0))) return rc;
+        const int npan = (r + ld - 1) / ld;
+        std::vector<cplx> Gh((size_t)ld * ld);
+        for (int which = 0; which < 2; ++which) {
+            cplx* out_host = (cplx*)(which == 0 ? Aq_host : Bq_host);
+            if (!out_host) continue;
+            std::vector<cplx> res((size_t)r * r, cmake(0, 0));
+            if (which == 1 && fh_b_identity(h) && hermitize && !bilinear) {
+                for (int i = 0; i < r; ++i) res[(size_t)i * r + i] = cmake(1, 0);
+            } else {
+                for (int j = 0; j < npan; ++j) {
+                    const int mj = std::min(ld, r - j * ld);
+                    fh_launch_to_panel((const cplx*)dQ + (size_t)j * ld * N, N, N, mj, Qj, ld, h->stream);
+                    fh_op_call oc;
+                    oc.m = mj;
+                    oc.X = Qj; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
+                    oc.coefA = which == 0 ? d1 : d0; oc.coefB = which == 0 ? d0 : d1;
+                    oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+                    oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+                    fh_apply_operator(h, ld, oc);
+                    for (int i = 0; i < npan; ++i) {
+                        const int mi = std::min(ld, r - i * ld);
+                        fh_launch_to_panel((const cplx*)dQ + (size_t)i * ld * N, N, N, mi, Qi, ld, h->stream);
+                        fh_prof_begin(h, "gram");
+                        fh_launch_gram(Qi, W, N, ld, bilinear, gw, G, h->stream);
+                        fh_prof_end(h);
+                        FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+                        FH_CHECK(hipStreamSynchronize(h->stream));
+                        for (int c2 = 0; c2 < mj; ++c2)
+                            for (int c1 = 0; c1 < mi; ++c1)
+                                res[(size_t)(j * ld + c2) * r + i * ld + c1] = Gh[(size_t)c2 * ld + c1];
+                    }
+                }
+                if (hermitize && !bilinear) fh_hermitize(res, r);
+            }
+            memcpy(out_host, res.data(), res.size() * sizeof(cplx));
+        }
+        fh_prof_collect(h);
+        return 0;
+    }
+
     int rc = fh_check_problem(h, r64);
     if (rc) return rc;
     if (!dQ || !Aq_host) { h->last_error = "project: null argument"; return FEASTHIP_ERROR_INTERNAL; }
@@ -1341,7 +1530,7 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
 }
 
 extern "C" int feasthip_project(feasthip_handle h, int64_t r, const void* Q, int bilinear, int hermitize, void* Aq, void* Bq) {
-    int rc = fh_check_problem(h, r);
+    int rc = fh_check_problem(h, r, 1);
     if (rc) return rc;
     if (!Q) { h->last_error = "project: null Q"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));
@@ -1356,6 +1545,109 @@ extern "C" int feasthip_project(feasthip_handle h, int64_t r, const void* Q, int
 extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const void* dQ, const void* V_host,
                                           const double* lambda_host, int64_t M, int normalize, int use_B, void* dX,
                                           double* res_host) {
+    if (r64 > FH_MAX_LD) {
+        // r > 64: X_j = sum_i Q_i V[i-block, j-block] per 64-column output panel, then the panel
+        // goes through the same normalise / residual steps as the narrow path
+        int rc0 = fh_check_problem(h, r64, 1);
+        if (rc0) return rc0;
+        if (!dQ || !V_host || !lambda_host || !dX) { h->last_error = "ritz_residual: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+        if (M < 0 || M > r64) { h->last_error = "ritz_residual: M out of range"; return FEASTHIP_ERROR_M0; }
+        if (dQ == dX) { h->last_error = "ritz_residual: X must not alias Q for r > 64"; return FEASTHIP_ERROR_INTERNAL; }
+        FH_CHECK(hipSetDevice(h->device));
+        const int r = (int)r64, ld = FH_MAX_LD, N = (int)fh_N(h);
+        const size_t panel = (size_t)N * ld;
+        void* p;
+        int rc;
+        if ((rc = fh_get_buf(h, "rz_Q", panel * sizeof(cplx), &p))) return rc;
+        cplx* Qp = (cplx*)p;
+        if ((rc = fh_get_buf(h, "rz_X", panel * sizeof(cplx), &p))) return rc;
+        cplx* Xp = (cplx*)p;
+        if ((rc = fh_get_buf(h, "rz_R", panel * sizeof(cplx), &p))) return rc;
+        cplx* Rp = (cplx*)p;
+        if ((rc = fh_get_buf(h, "rz_T", panel * sizeof(cplx), &p))) return rc;
+        cplx* Tp = (cplx*)p;
+        if ((rc = fh_get_buf(h, "rz_V", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+        cplx* dV = (cplx*)p;
+        const int nblk_op = fh_op_nblk(h, ld), nblk_vec = fh_vec_nblk(N, ld);
+        if ((rc = fh_get_buf(h, "rz_part", (size_t)std::max(nblk_op, nblk_vec) * ld * sizeof(cplx), &p))) return rc;
+        cplx* part = (cplx*)p;
+        if ((rc = fh_get_buf(h, "rz_dots", (size_t)ld * sizeof(cplx), &p))) return rc;
+        cplx* ddots = (cplx*)p;
+        std::vector<cplx> mones(ld, cmake(-1, 0));
+        cplx* dmone;
+        if ((rc = fh_upload_coefs(h, "rz_mone", mones, &dmone))) return rc;
+        const cplx* Vh = (const cplx*)V_host;
+        const int npan = (r + ld - 1) / ld;
+        std::vector<cplx> Vp((size_t)ld * ld), dots(ld);
+        for (int j = 0; j < npan; ++j) {
+            const int mj = std::min(ld, r - j * ld);
+            for (int i = 0; i < npan; ++i) {
+                const int mi = std::min(ld, r - i * ld);
+                std::fill(Vp.begin(), Vp.end(), cmake(0, 0));
+                for (int c2 = 0; c2 < mj; ++c2)
+                    for (int c1 = 0; c1 < mi; ++c1) Vp[(size_t)c2 * ld + c1] = Vh[(size_t)(j * ld + c2) * r + i * ld + c1];
+                FH_CHECK(hipMemcpyAsync(dV, Vp.data(), Vp.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+                fh_launch_to_panel((const cplx*)dQ + (size_t)i * ld * N, N, N, mi, Qp, ld, h->stream);
+                fh_prof_begin(h, "ritz");
+                if (i == 0) {
+                    fh_launch_small_matmul(Qp, dV, N, ld, Xp, h->stream);
+                } else {
+                    fh_launch_small_matmul(Qp, dV, N, ld, Tp, h->stream);
+                    fh_launch_axpy_cols(Xp, Tp, dmone, N, ld, h->stream);      // X += T
+                }
+                fh_prof_end(h);
+                FH_CHECK(hipStreamSynchronize(h->stream));                      // Vp (host) is reused
+            }
+            const int Mj = std::max(0, std::min(mj, (int)M - j * ld));          // columns of this panel below M
+            if (normalize && Mj > 0) {
+                fh_launch_dot_cols(Xp, Xp, N, ld, part, ddots, h->stream);
+                FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+                FH_CHECK(hipStreamSynchronize(h->stream));
+                std::vector<cplx> sc(ld, cmake(1, 0));
+                for (int c = 0; c < Mj; ++c) {
+                    double n = std::sqrt(dots[c].x);
+                    if (n > 0) sc[c] = cmake(1.0 / n, 0);
+                }
+                cplx* dsc;
+                if ((rc = fh_upload_coefs(h, "rz_scale", sc, &dsc))) return rc;
+                fh_launch_scale_cols(Xp, dsc, N, ld, h->stream);
+            }
+            fh_launch_from_panel(Xp, ld, N, mj, (cplx*)dX + (size_t)j * ld * N, N, h->stream);
+            if (Mj > 0 && res_host) {
+                const double* lam = lambda_host + 2 * (size_t)j * ld;
+                std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
+                const bool lam_in_op = use_B || fh_b_identity(h);
+                for (int c = 0; c < mj; ++c) cb[c] = lam_in_op ? cmake(-lam[2 * c], -lam[2 * c + 1]) : cmake(0, 0);
+                cplx *dca, *dcb;
+                if ((rc = fh_upload_coefs(h, "rz_coefA", ca, &dca))) return rc;
+                if ((rc = fh_upload_coefs(h, "rz_coefB", cb, &dcb))) return rc;
+                fh_op_call oc;
+                oc.m = mj;
+                oc.X = Xp; oc.x_stride = 0; oc.Y = Rp; oc.y_stride = 0; oc.coefA = dca; oc.coefB = dcb;
+                oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+                oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+                fh_apply_operator(h, ld, oc);
+                if (!use_B && !fh_b_identity(h)) {
+                    std::vector<cplx> lv(ld, cmake(0, 0));
+                    for (int c = 0; c < mj; ++c) lv[c] = cmake(lam[2 * c], lam[2 * c + 1]);
+                    cplx* dl;
+                    if ((rc = fh_upload_coefs(h, "rz_lam", lv, &dl))) return rc;
+                    fh_launch_axpy_cols(Rp, Xp, dl, N, ld, h->stream);
+                }
+                fh_launch_dot_cols(Rp, Rp, N, ld, part, ddots, h->stream);
+                FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+                FH_CHECK(hipStreamSynchronize(h->stream));
+                for (int c = 0; c < Mj; ++c) {
+                    double la = std::hypot(lam[2 * c], lam[2 * c + 1]);
+                    res_host[j * ld + c] = std::sqrt(dots[c].x) / std::max(la, 1.0);
+                }
+            }
+        }
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        fh_prof_collect(h);
+        return 0;
+    }
+
     int rc = fh_check_problem(h, r64);
     if (rc) return rc;
     if (!dQ || !V_host || !lambda_host || !dX) { h->last_error = "ritz_residual: null argument"; return FEASTHIP_ERROR_INTERNAL; }
@@ -1439,7 +1731,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
 
 extern "C" int feasthip_ritz_residual(feasthip_handle h, int64_t r, const void* Q, const void* V, const double* lambda,
                                       int64_t M, int normalize, int use_B, void* X, double* res) {
-    int rc = fh_check_problem(h, r);
+    int rc = fh_check_problem(h, r, 1);
     if (rc) return rc;
     if (!Q || !X) { h->last_error = "ritz_residual: null argument"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));
@@ -1457,6 +1749,18 @@ extern "C" int feasthip_ritz_residual(feasthip_handle h, int64_t r, const void* 
 // RCI seams: Y = A X / B X (jobs 30/40), Y = (zB - A)^{-1} X (jobs 10+11, linear_solver)
 // ---------------------------------------------------------------------------------------
 extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, const void* dX, void* dY) {
+    if (m64 > FH_MAX_LD) {          // independent columns: 64 at a time
+        int rc0 = fh_check_problem(h, m64, 1);
+        if (rc0) return rc0;
+        const size_t N0 = (size_t)fh_N(h);
+        for (int64_t c0 = 0; c0 < m64; c0 += FH_MAX_LD) {
+            const int64_t mc = std::min<int64_t>(FH_MAX_LD, m64 - c0);
+            rc0 = feasthip_matmul_dev(h, which, mc, (const cplx*)dX + c0 * N0, (cplx*)dY + c0 * N0);
+            if (rc0) return rc0;
+        }
+        return 0;
+    }
+
     int rc = fh_check_problem(h, m64);
     if (rc) return rc;
     if (!dX || !dY || (which != 0 && which != 1)) { h->last_error = "matmul: bad argument"; return FEASTHIP_ERROR_INTERNAL; }
@@ -1486,7 +1790,7 @@ extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, co
 }
 
 extern "C" int feasthip_matmul(feasthip_handle h, int which, int64_t m, const void* X, void* Y) {
-    int rc = fh_check_problem(h, m);
+    int rc = fh_check_problem(h, m, 1);
     if (rc) return rc;
     if (!X || !Y) { h->last_error = "matmul: null argument"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));
@@ -1502,6 +1806,26 @@ extern "C" int feasthip_matmul(feasthip_handle h, int which, int64_t m, const vo
 
 extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double z_im, int64_t m64, const void* dX,
                                           void* dY, feasthip_stats* stats) {
+    if (m64 > FH_MAX_LD) {          // independent right-hand sides: 64 at a time (LU factor cached between panels)
+        int rc0 = fh_check_problem(h, m64, 1);
+        if (rc0) return rc0;
+        const size_t N0 = (size_t)fh_N(h);
+        feasthip_stats tot;
+        memset(&tot, 0, sizeof(tot));
+        int worst = 0;
+        for (int64_t c0 = 0; c0 < m64; c0 += FH_MAX_LD) {
+            const int64_t mc = std::min<int64_t>(FH_MAX_LD, m64 - c0);
+            feasthip_stats st;
+            rc0 = feasthip_shifted_solve_dev(h, z_re, z_im, mc, (const cplx*)dX + c0 * N0, (cplx*)dY + c0 * N0, &st);
+            if (rc0 != 0 && rc0 != FEASTHIP_ERROR_NO_CONVERGENCE && rc0 != FEASTHIP_ERROR_LAPACK) return rc0;
+            worst = std::max(worst, rc0);
+            tot.krylov_iterations += st.krylov_iterations; tot.spmm_calls += st.spmm_calls; tot.factorizations += st.factorizations;
+            tot.max_rel_residual = std::max(tot.max_rel_residual, st.max_rel_residual);
+        }
+        if (stats) *stats = tot;
+        return worst;
+    }
+
     int rc = fh_check_problem(h, m64);
     if (rc) return rc;
     if (!dX || !dY) { h->last_error = "shifted_solve: null argument"; return FEASTHIP_ERROR_INTERNAL; }
@@ -1551,7 +1875,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
 
 extern "C" int feasthip_shifted_solve(feasthip_handle h, double z_re, double z_im, int64_t m, const void* X, void* Y,
                                       feasthip_stats* stats) {
-    int rc = fh_check_problem(h, m);
+    int rc = fh_check_problem(h, m, 1);
     if (rc) return rc;
     if (!X || !Y) { h->last_error = "shifted_solve: null argument"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));

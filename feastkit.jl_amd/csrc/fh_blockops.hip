@@ -336,7 +336,8 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mgs_norms(const cplx* __restrict__
 // choose next pivot from column norms (sum of partials); one block
 template <int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_mgs_pick(const cplx* __restrict__ partial, int nblk, int N, int m,
-                                                        double rank_tol, int* istate, double* dstate) {
+                                                        double rank_tol, double ref_scale, int big_dim, int* istate,
+                                                        double* dstate) {
     __shared__ cplx red[FH_BLOCK];
     __shared__ double nrm[LD];
     const int t = threadIdx.x, c = t % LD, g = t / LD;
@@ -365,11 +366,14 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mgs_pick(const cplx* __restrict__ 
         }
         double rkk = (bp >= 0) ? sqrt(best) : 0.0;
         if (k == 0) {
-            dstate[0] = rkk;
+            // ref_scale > 0: this panel is a block of a wider matrix whose largest column norm
+            // (the R_11 of the reference's pivoted QR) was found by the caller
+            const double r11 = rkk > ref_scale ? rkk : ref_scale;
+            dstate[0] = r11;
             double eps = 2.220446049250313e-16;
-            double big = (double)(N > m ? N : m);
+            double big = (double)(N > big_dim ? N : big_dim);
             double th = rank_tol > eps * big ? rank_tol : eps * big;
-            dstate[1] = th * rkk;
+            dstate[1] = th * r11;
         }
         if (bp < 0 || !(rkk > dstate[1]) || rkk == 0.0) {
             istate[2] = 1;           // done: rank = k
@@ -488,7 +492,7 @@ static void mgs_run_ld(const fh_mgs_args& a, hipStream_t st) {
     hipLaunchKernelGGL(k_mgs_init, dim3(1), dim3(128), 0, st, a.istate, LD);
     hipLaunchKernelGGL((k_mgs_norms<LD>), dim3(nblk_flat), dim3(FH_BLOCK), 0, st, a.X, total, a.work);
     hipLaunchKernelGGL((k_mgs_pick<LD>), dim3(1), dim3(FH_BLOCK), 0, st, a.work, nblk_flat, a.N, a.m, a.rank_tol,
-                       a.istate, a.dstate);
+                       a.ref_scale, a.big_dim > a.m ? a.big_dim : a.m, a.istate, a.dstate);
     for (int k = 0; k < a.m; ++k) {
         // first projection pass (no normalisation), then re-orthogonalise and normalise pivot
         for (int pass = 0; pass < 2; ++pass) {
@@ -501,7 +505,7 @@ static void mgs_run_ld(const fh_mgs_args& a, hipStream_t st) {
         hipLaunchKernelGGL(k_mgs_advance, dim3(1), dim3(64), 0, st, a.istate, a.m);
         // norms of the remaining columns come from the last update's partials
         hipLaunchKernelGGL((k_mgs_pick<LD>), dim3(1), dim3(FH_BLOCK), 0, st, a.work, nblk, a.N, a.m, a.rank_tol,
-                           a.istate, a.dstate);
+                           a.ref_scale, a.big_dim > a.m ? a.big_dim : a.m, a.istate, a.dstate);
     }
 }
 

@@ -106,6 +106,8 @@ struct fh_mgs_args {
     int* istate; double* dstate; cplx* coef;   // coef[ld]
     cplx* work;                                // nblk*ld partials
     double rank_tol;
+    double ref_scale = 0.0;                    // external R_11 (block of a wider matrix), 0 = own first pivot
+    int big_dim = 0;                           // total column count of the wider matrix (eps*max(N,M0) term)
 };
 void fh_mgs_run(const fh_mgs_args& a, hipStream_t st);
 

@@ -111,8 +111,6 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     info = check_feast_srci_input(N, M0, Emin, Emax)
     if info:
         return FeastResult(np.zeros(0), np.zeros((N, 0), dtype=np.complex128), 0, np.zeros(0), info, math.inf, 0)
-    if M0 > 64:
-        raise ValueError("the :hip backend currently takes M0 <= 64 per call (FH_MAX_LD)")
     rank, world = _world(group)
     iterative = solver not in ("direct", "lu")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
@@ -303,8 +301,6 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
         return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 2, math.inf, 0)
     if not r > 0:
         return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 4, math.inf, 0)
-    if M0 > 64:
-        raise ValueError("the :hip backend currently takes M0 <= 64 per call (FH_MAX_LD)")
     rank, world = _world(group)
     iterative = solver not in ("direct", "lu")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
@@ -388,8 +384,6 @@ def feast_hip_complex_symmetric(engine, A, B, Emid, r, M0, fpm, *, solver="direc
         return empty(2)
     if not r > 0:
         return empty(4)
-    if M0 > 64:
-        raise ValueError("the :hip backend currently takes M0 <= 64 per call (FH_MAX_LD)")
     for name, Mx in (("A", A), ("B", B)):
         if Mx is None:
             continue

@@ -138,8 +138,9 @@ int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
 
 /* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
  * (src/dense/feast_dense.jl:81-84).  Iterative stop test is Krylov.jl's
- * ||r_k|| <= atol + rtol*||r_0|| per column.  factor_precision 64|32 (dense LU only;
- * 32 = c64 factors + fp64 iterative refinement).  cache_factors: keep LU factors per
+ * ||r_k|| <= atol + rtol*||r_0|| per column.  factor_precision 64|32: 32 runs the BiCGStab/COCG
+ * correction solve on complex64 panels around an fp64 residual (CSR input, inexact-solve mode);
+ * the dense LU path always factors in complex128.  cache_factors: keep LU factors per
  * node across calls (src/dense/feast_dense.jl:147,188).                                 */
 int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit,
                          int restart, int factor_precision, int cache_factors);
@@ -148,7 +149,8 @@ int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, 
 /* One contour sweep over this handle's node range:
  *     for e in local nodes:  Y_e = (z_e B - A)^{-1} (B Q);   Qproj += weight_scale*w_e*Y_e
  *     optionally  zAq += weight_scale*w_e * Q^H Y_e,  zSq += weight_scale*w_e*z_e * Q^H Y_e
- * Q, Qproj: N x m c128 column-major (ldq = N).  Qproj is OVERWRITTEN with this handle's
+ * Q, Qproj: N x m c128 column-major (ldq = N), 1 <= m <= N; m > 64 is processed in 64-column
+ * panels (this holds for every entry point below; zAq/zSq need m <= 64).  Qproj is OVERWRITTEN with this handle's
  * partial sum (callers reduce across handles/ranks: src/parallel/feast_parallel.jl:497-503,
  * src/parallel/feast_mpi.jl:117-119).  zAq/zSq: m x m c128 or NULL.
  * ritz_lambda: NULL => zero initial guess (reference behaviour, Krylov.jl gmres);

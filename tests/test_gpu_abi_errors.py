@@ -160,4 +160,4 @@ def test_column_mask_keeps_initial_guess(engine):
             want = sum(2 * W[e] * np.linalg.solve(Sd[e], B @ Q[:, c]) for e in range(4))
         assert np.allclose(P[:, c], want, atol=1e-9), c
     lib = engine.lib
-    assert lib.feasthip_set_column_mask(engine.h, 65, None) == 2
+    assert lib.feasthip_set_column_mask(engine.h, -1, None) == 2

@@ -385,3 +385,48 @@ def test_complex_symmetric_sparse_bicgstab(engine):
     key = lambda x: (round(x.real, 6), round(x.imag, 6))
     assert np.allclose(sorted(got.lambda_, key=key), sorted(inside, key=key), atol=1e-8)
     assert got.epsout <= 1e-10
+
+
+# ---- M0 > 64: every entry point works panel by panel (64 columns) ---------------------------------
+def test_wide_subspace_dense_and_sparse(engine):
+    """M0 > 64.  Dense LU path: 80 clustered eigenvalues + a far-away rest (the 100-column subspace is
+    compressed to rank ~80), then a uniformly dense spectrum where the reference algorithm stagnates
+    on spurious Ritz values -- the GPU path must stagnate identically.  CSR + COCG: ~75 wanted."""
+    N = 500
+    lo, hi = 1.005, 1.805
+    want = 0.01 * np.arange(101, 181)
+    A = fo.householder_conjugated_diag(np.concatenate([want, np.linspace(3.0, 10.0, N - 80)]))
+    r = fk.feast(A, None, (lo, hi), M0=100, fpm=fpm_with(f2=8), engine=engine)
+    assert r.info == 0 and r.M == 80 and np.allclose(np.sort(r.lambda_), want, atol=1e-10)
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert res.max() <= 1e-10
+    o = fo.feast_hermitian(A, None, lo, hi, 100, ne=8, real_projection=True)
+    assert o.info == 0 and o.M == 80 and abs(o.loop - r.loop) <= 1
+    A2 = fo.householder_conjugated_diag(0.01 * np.arange(N))
+    r8 = fk.feast(A2, None, (lo, hi), M0=100, fpm=fpm_with(f2=8, f4=4), engine=engine)
+    o8 = fo.feast_hermitian(A2, None, lo, hi, 100, ne=8, fpm4=4, real_projection=True)
+    assert (r8.info, r8.M, r8.loop) == (o8.info, o8.M, o8.loop) == (5, 81, 4)
+    assert abs(r8.epsout - o8.epsout) <= 1e-6 * o8.epsout
+    # sparse generalized, warm-started inexact COCG, Ritz warm start sliced per panel
+    As, Bs, lam = fo.cfg3_problem(14, 12, 10)
+    hi = 0.5 * (lam[74] + lam[75])
+    inside = lam[:75]
+    rs = fk.feast_hip_hermitian(engine, As, Bs, 0.0, hi, 95, fpm_with(f2=8, f4=40), solver="cocg", warm_start=True,
+                                inner_rtol=1e-2, solver_maxiter=300, real_projection=True)
+    assert rs.info == 0 and rs.M == 75 and np.allclose(np.sort(rs.lambda_), inside, atol=1e-10)
+    assert rs.epsout <= 1e-12
+
+
+def test_wide_general_dense(engine):
+    """Variant C with M0 = 80 (> 64) on a non-Hermitian dense matrix."""
+    n = 300
+    rng = np.random.default_rng(12)
+    d = np.concatenate([0.9 * np.sqrt(rng.random(70)) * np.exp(2j * np.pi * rng.random(70)),
+                        (2.0 + 3.0 * rng.random(n - 70)) * np.exp(2j * np.pi * rng.random(n - 70))])
+    S = rng.standard_normal((n, n)) + n * np.eye(n)
+    A = S @ np.diag(d) @ np.linalg.inv(S)
+    r = fk.feast_general(A, None, 0.0 + 0.0j, 1.2, M0=80, fpm=fpm_with(f8=16), engine=engine)
+    inside = d[np.abs(d) <= 1.2]
+    assert r.info == 0 and r.M == len(inside) == 70
+    key = lambda x: (round(x.real, 6), round(x.imag, 6))
+    assert np.allclose(sorted(r.lambda_, key=key), sorted(inside, key=key), atol=1e-8)

@@ -33,7 +33,7 @@ def sparse_pair(N, seed, cplx=False, b_identity=False):
     return A, sp.csr_matrix(B)
 
 
-@pytest.mark.parametrize("N,m", [(50, 3), (257, 16), (1000, 17), (777, 32), (513, 48), (2049, 64)])
+@pytest.mark.parametrize("N,m", [(50, 3), (257, 16), (1000, 17), (777, 32), (513, 48), (2049, 64), (640, 100)])
 @pytest.mark.parametrize("cplx,bid", [(False, False), (True, False), (False, True)])
 def test_spmm_matches_scipy(engine, N, m, cplx, bid):
     A, B = sparse_pair(N, 11 + N + m, cplx, bid)
@@ -68,7 +68,7 @@ def test_dense_matmul(engine, N, m, cplx, bid):
     assert np.abs(YB - refB).max() <= 1e-11 * np.abs(refB).max()
 
 
-@pytest.mark.parametrize("N,m", [(40, 5), (300, 16), (1000, 32), (2000, 64)])
+@pytest.mark.parametrize("N,m", [(40, 5), (300, 16), (1000, 32), (2000, 64), (900, 65), (1500, 150)])   # m > 64: panels
 def test_project_matches_numpy(engine, N, m):
     A, B = sparse_pair(N, 3, cplx=True)
     engine.set_problem(A, B)
@@ -85,7 +85,8 @@ def test_project_matches_numpy(engine, N, m):
     assert np.abs(At - Q.T @ (A @ Q)).max() <= 1e-11 * np.abs(refA).max()
 
 
-@pytest.mark.parametrize("N,m,true_rank", [(30, 4, 4), (200, 16, 9), (1000, 32, 32), (3000, 64, 40), (500, 10, 3)])
+@pytest.mark.parametrize("N,m,true_rank", [(30, 4, 4), (200, 16, 9), (1000, 32, 32), (3000, 64, 40), (500, 10, 3),
+                                           (800, 100, 100), (1200, 130, 70), (600, 200, 64)])   # m > 64: block Gram-Schmidt
 def test_orthonormalize_rank_and_span(engine, N, m, true_rank):
     A, B = sparse_pair(N, 3)
     engine.set_problem(A, B)
@@ -117,7 +118,7 @@ def test_orthonormalize_reference_kat(engine):
     assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= 1e-12 * np.linalg.norm(src)
 
 
-@pytest.mark.parametrize("N,r,M", [(60, 6, 3), (400, 16, 16), (1500, 30, 11), (2500, 64, 44)])
+@pytest.mark.parametrize("N,r,M", [(60, 6, 3), (400, 16, 16), (1500, 30, 11), (2500, 64, 44), (700, 100, 80), (1000, 129, 129)])
 @pytest.mark.parametrize("use_B", [True, False])
 def test_ritz_residual(engine, N, r, M, use_B):
     A, B = sparse_pair(N, 21)
