@@ -99,6 +99,7 @@ int fh_kry_nblk(int N, int ld, int nodes) {
     size_t total = (size_t)N * ld;
     size_t nb = (total + FH_BLOCK * 4 - 1) / (FH_BLOCK * 4);
     size_t cap = 2048 / (size_t)(nodes < 1 ? 1 : (nodes > 8 ? 8 : nodes));
+    if (cap > 512) cap = 512;      // 1-2 local nodes (8-GPU runs): the finalize kernel walks every partial row
     if (nb > cap) nb = cap;
     if (nb < 8) nb = 8;
     return (int)((nb + 7) / 8 * 8);

@@ -18,7 +18,7 @@ eng.set_node_range(0, nodes)
 eng.set_solver(os.environ.get("SOLVER","bicgstab"), rtol=0.0, atol=0.0, maxit=maxit, factor_precision=int(os.environ.get("PREC","64")))
 Q = eng.upload(fk.seeded_subspace(50000, 64))
 eng.contour_apply(Q, 64)
-eng.profile_reset(); eng.profile_enable(True)
+eng.profile_reset(); eng.profile_enable(os.environ.get('NOPROF') is None)
 t0 = time.perf_counter()
 for _ in range(reps):
     dP, status, st = eng.contour_apply(Q, 64)
