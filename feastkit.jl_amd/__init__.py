@@ -18,6 +18,8 @@ from .engine import HipEngine   # noqa: F401
 from .api import feast, feast_general   # noqa: F401
 from . import rci   # noqa: F401
 from . import ingest   # noqa: F401
+from . import banded   # noqa: F401
+from .banded import feast_sbgv, feast_sbev, feast_hbgv, feast_hbev, feast_gbgv, feast_gbev   # noqa: F401
 from .rci import (RciRefs, RciState, HipRciServer, feast_srci, feast_hrci, feast_grci,   # noqa: F401
                   rci_solve_symmetric, rci_solve_hermitian, rci_solve_general)
 

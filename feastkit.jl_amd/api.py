@@ -21,6 +21,24 @@ def _is_hermitian(A, tol=0.0):
     return np.array_equal(A, A.conj().T)
 
 
+def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30):
+    """``solver=:direct`` for sparse input: "banded" when the union pattern of A and B is a narrow band
+    whose LU factors (2 kl + ku + 1 rows per column and node, complex128) fit the budget, else the
+    Krylov default."""
+    kl = ku = 0
+    for M in (A, B):
+        if M is None:
+            continue
+        c = sp.coo_matrix(M)
+        if c.nnz:
+            kl = max(kl, int((c.row - c.col).max()))
+            ku = max(ku, int((c.col - c.row).max()))
+    ldab = 2 * kl + ku + 1
+    if 2 * kl + ku + 1 <= 3500 and ldab * A.shape[0] * 16 * max(nodes, 1) <= budget_bytes and kl + ku <= 512:
+        return "banded"
+    return "bicgstab"
+
+
 def _engine(engine, device):
     return engine if engine is not None else HipEngine(device)
 
@@ -52,9 +70,9 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
     real_input = not (np.iscomplexobj(A.data if sp.issparse(A) else A) or
                       (B is not None and np.iscomplexobj(B.data if sp.issparse(B) else B)))
     if sp.issparse(A) and solver in ("direct", "lu"):
-        # the reference's sparse default is UMFPACK; the :hip backend replaces it with the
-        # batched Krylov solver (north_star) -- there is no sparse direct factorisation here
-        solver = "bicgstab"
+        # the reference's sparse default is UMFPACK; the :hip backend has a direct path for band
+        # matrices (batched banded LU) and otherwise the batched Krylov solver (north_star)
+        solver = _sparse_direct_solver(A, B, int(fpm[2]))
     eng = _engine(engine, device)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
@@ -78,7 +96,7 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
     feastdefault(fpm)
     M0 = min(int(M0), A.shape[0])
     if sp.issparse(A) and solver in ("direct", "lu"):
-        solver = "bicgstab"
+        solver = _sparse_direct_solver(A, B, int(fpm[8]))
     eng = _engine(engine, device)
     return feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver,
                              solver_tol=solver_tol, solver_maxiter=solver_maxiter,

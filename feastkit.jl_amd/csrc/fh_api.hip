@@ -3,6 +3,7 @@
 #include "fh_common.hpp"
 #include "fh_kernels.hpp"
 #include "fh_dense.hpp"
+#include "fh_banded.hpp"
 #include "../../include/feasthip.h"
 
 #include <algorithm>
@@ -133,6 +134,7 @@ static void fh_free_problem(feasthip_ctx* h) {
     for (void* p : h->lu_factors) if (p) hipFree(p);
     for (int* p : h->lu_pivots) if (p) hipFree(p);
     h->lu_factors.clear(); h->lu_pivots.clear(); h->lu_valid.clear(); h->lu_z.clear();
+    fh_banded_free(h);
     h->kind = 0;
 }
 
@@ -260,7 +262,14 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
         if (col.size() > (size_t)INT32_MAX) { h->last_error = "feasthip_set_csr: nnz exceeds int32"; return FEASTHIP_ERROR_MEMORY; }
         rowptr[i + 1] = (int)col.size();
     }
+    int kl_ = 0, ku_ = 0;
+    for (int64_t i = 0; i < N; ++i)
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            kl_ = std::max(kl_, (int)(i - col[k]));
+            ku_ = std::max(ku_, (int)(col[k] - i));
+        }
     fh_free_problem(h);
+    h->csr_kl = kl_; h->csr_ku = ku_;
     fh_csr& d = h->csr;
     d.N = N; d.nnz = (int64_t)col.size(); d.is_complex = sizeof(VT) == sizeof(cplx); d.b_identity = hasB ? 0 : 1;
     FH_CHECK(hipMalloc((void**)&d.rowptr, (N + 1) * sizeof(int)));
@@ -328,6 +337,7 @@ extern "C" int feasthip_set_contour(feasthip_handle h, int ne, const double* zne
     for (int e = 0; e < ne; ++e) h->node_ids[e] = e;
     // cached factors belong to the old contour
     for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
+    for (size_t i = 0; i < h->band_valid.size(); ++i) h->band_valid[i] = 0;
     return 0;
 }
 
@@ -348,6 +358,7 @@ extern "C" int feasthip_set_node_range(feasthip_handle h, int first, int count) 
     h->node_ids.resize(count);
     for (int e = 0; e < count; ++e) h->node_ids[e] = first + e;
     for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
+    for (size_t i = 0; i < h->band_valid.size(); ++i) h->band_valid[i] = 0;
     return 0;
 }
 
@@ -363,6 +374,7 @@ extern "C" int feasthip_set_node_list(feasthip_handle h, int count, const int* i
     h->node_first = count > 0 ? indices[0] : 0;
     h->node_count = count;
     for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
+    for (size_t i = 0; i < h->band_valid.size(); ++i) h->band_valid[i] = 0;
     return 0;
 }
 
@@ -377,7 +389,7 @@ extern "C" int feasthip_set_column_mask(feasthip_handle h, int64_t m, const int*
 extern "C" int feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit, int restart,
                                    int factor_precision, int cache_factors) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
-    if (kind < 0 || kind > 3 || rtol < 0 || atol < 0 || maxit <= 0 || restart < 0 ||
+    if (kind < 0 || kind > 4 || rtol < 0 || atol < 0 || maxit <= 0 || restart < 0 ||
         (factor_precision != 64 && factor_precision != 32)) {
         h->last_error = "feasthip_set_solver: invalid option";
         return FEASTHIP_ERROR_FPM;
@@ -931,6 +943,11 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix (sparse direct factorisation is not provided; use BICGSTAB)"; return FEASTHIP_ERROR_FPM; }
         int64_t nfact = 0;
         rc = fh_dense_lu_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
+        if (rc) return rc;
+        if (stats) stats->factorizations = nfact;
+    } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
+        int64_t nfact = 0;
+        rc = fh_banded_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
         if (rc) return rc;
         if (stats) stats->factorizations = nfact;
     } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB || h->solver == FEASTHIP_SOLVER_COCG) {
@@ -1846,6 +1863,11 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         int64_t nfact = 0;
         // cached per quadrature node when z is one, else in one extra slot
         rc = fh_dense_lu_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
+        if (rc) return rc;
+        if (stats) stats->factorizations = nfact;
+    } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
+        int64_t nfact = 0;
+        rc = fh_banded_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;
         if (stats) stats->factorizations = nfact;
     } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB || h->solver == FEASTHIP_SOLVER_COCG) {

@@ -1,0 +1,309 @@
+// Batched banded LU (ZGBTRF / ZGBTRS semantics) for CSR input with a narrow band: the direct solver
+// of the reference's banded drivers (LAPACK.gbtrf!/gbtrs!, src/banded/feast_banded.jl:100-150) and
+// a sparse DIRECT path for band matrices (the reference's sparse default is UMFPACK,
+// src/sparse/feast_sparse.jl:339, which is not replicated).
+//
+// Storage per quadrature node: LAPACK general band storage AB(ldab, N), ldab = 2 kl + ku + 1,
+//   A(i, j) = AB[kv + i - j + j * ldab],  kv = kl + ku,   max(0, j - ku) <= i <= min(N - 1, j + kl),
+// the first kl rows are the fill-in space of the row interchanges; complex128, 0-based here.
+// One workgroup per node walks the columns (the elimination is inherently sequential in j; the
+// parallelism is nodes x the (kl x (kl+ku)) window, and nodes x right-hand sides in the solves).
+#include <algorithm>
+#include <vector>
+
+#include "fh_banded.hpp"
+#include "../../include/feasthip.h"
+
+#define FH_BLOCK 256
+#define BAND_THREADS 512
+
+// AB = z B - A from the CSR arrays (A and B share the union pattern); AB was zeroed by the caller
+template <typename VT, bool BIDENT>
+__global__ __launch_bounds__(FH_BLOCK) void k_band_form(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const VT* __restrict__ aval, const VT* __restrict__ bval,
+                                                         cplx* const* ABs, const cplx* z, int N, int kl, int ku) {
+    cplx* AB = ABs[blockIdx.y];
+    const cplx zz = z[blockIdx.y];
+    const int ldab = 2 * kl + ku + 1, kv = kl + ku;
+    const int i = blockIdx.x * FH_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    if (BIDENT) AB[kv + (size_t)i * ldab] = zz;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int j = col[k];
+        cplx a;
+        if constexpr (sizeof(VT) == sizeof(cplx)) a = cmake(aval[k].x, aval[k].y); else a = cmake(aval[k], 0.0);
+        cplx* dst = AB + (size_t)j * ldab + kv + i - j;
+        if (BIDENT) {
+            *dst = csub(*dst, a);
+        } else {
+            cplx b;
+            if constexpr (sizeof(VT) == sizeof(cplx)) b = cmake(bval[k].x, bval[k].y); else b = cmake(bval[k], 0.0);
+            *dst = csub(cmul(zz, b), a);
+        }
+    }
+}
+
+// Unblocked band LU with partial pivoting (ZGBTF2): pivot rule IZAMAX (max |re|+|im|, lowest index on
+// ties) among the kl+1 candidates of the column; the rank-1 update always spans the full kl+ku
+// columns to the right (LAPACK trims it to `ju`; the extra entries are zeros).
+__global__ __launch_bounds__(BAND_THREADS) void k_band_lu(cplx* const* ABs, int* const* pivs, int N, int kl, int ku,
+                                                          int* info) {
+    cplx* AB = ABs[blockIdx.x];
+    int* ipiv = pivs[blockIdx.x];
+    const int ldab = 2 * kl + ku + 1, kv = kl + ku;
+    const int t = threadIdx.x;
+    extern __shared__ cplx sm[];
+    cplx* lmul = sm;                 // [kl]      multipliers of the current column
+    cplx* urow = sm + kl;            // [kv + 1]  pivot row, columns j .. j + kv
+    __shared__ int s_jp;
+    for (int j = 0; j < N; ++j) {
+        const int km = min(kl, N - 1 - j);
+        const int nc = min(kv, N - 1 - j) + 1;
+        cplx* colj = AB + (size_t)j * ldab + kv;          // A(j + r, j) = colj[r]
+        if (t < 64) {
+            double best = -1.0;
+            int br = 0x7fffffff;
+            for (int r = t; r <= km; r += 64) {
+                const cplx v = colj[r];
+                const double m = fabs(v.x) + fabs(v.y);
+                if (m > best) { best = m; br = r; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(best, off);
+                const int orr = __shfl_xor(br, off);
+                if (o > best || (o == best && orr < br)) { best = o; br = orr; }
+            }
+            if (t == 0) {
+                s_jp = br == 0x7fffffff ? 0 : br;
+                ipiv[j] = j + s_jp;
+                if ((!(best > 0.0) || !isfinite(best)) && info[blockIdx.x] == 0) info[blockIdx.x] = j + 1;
+            }
+        }
+        __syncthreads();
+        const int jp = s_jp;
+        // row interchange over columns j .. j + nc - 1, pivot row kept in LDS
+        for (int cc = t; cc < nc; cc += BAND_THREADS) {
+            cplx* pc = AB + (size_t)(j + cc) * ldab + kv - cc;     // A(j, j + cc)
+            const cplx top = pc[0], piv = pc[jp];
+            if (jp != 0) { pc[0] = piv; pc[jp] = top; }
+            urow[cc] = piv;
+        }
+        __syncthreads();
+        const cplx pv = urow[0];
+        const bool singular = (pv.x == 0.0 && pv.y == 0.0);
+        const cplx inv = singular ? cmake(0, 0) : cdiv(cmake(1, 0), pv);
+        for (int r = 1 + t; r <= km; r += BAND_THREADS) {
+            const cplx l = cmul(colj[r], inv);
+            colj[r] = l;
+            lmul[r - 1] = l;
+        }
+        __syncthreads();
+        // A(j + r, j + cc) -= l_r * u_cc
+        const int work = km * (nc - 1);
+        for (int e = t; e < work; e += BAND_THREADS) {
+            const int r = 1 + e % km, cc = 1 + e / km;
+            cplx* p = AB + (size_t)(j + cc) * ldab + kv - cc + r;
+            *p = csub(*p, cmul(lmul[r - 1], urow[cc]));
+        }
+        __syncthreads();
+    }
+}
+
+// Y[node] = RHS (shared right-hand side panel, row-major N x ld)
+__global__ __launch_bounds__(FH_BLOCK) void k_band_copy_rhs(const cplx* __restrict__ RHS, cplx* __restrict__ Y, size_t stride,
+                                                             size_t total) {
+    cplx* Yn = Y + (size_t)blockIdx.y * stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) Yn[e] = RHS[e];
+}
+
+// ZGBTRS on a row-major N x ld panel: one workgroup per (16-column tile, node); thread = (row lane, column)
+__global__ __launch_bounds__(FH_BLOCK) void k_band_solve(cplx* const* ABs, int* const* pivs, cplx* Y, size_t stride, int N,
+                                                          int ld, int kl, int ku) {
+    const cplx* AB = ABs[blockIdx.y];
+    const int* ipiv = pivs[blockIdx.y];
+    cplx* Yn = Y + (size_t)blockIdx.y * stride + 16 * blockIdx.x;
+    const int ldab = 2 * kl + ku + 1, kv = kl + ku;
+    const int c = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    constexpr int RL = FH_BLOCK / 16;
+    // forward: L y = P b, interchanges applied on the fly
+    for (int j = 0; j < N; ++j) {
+        const int km = min(kl, N - 1 - j);
+        const int p = ipiv[j];
+        if (p != j && rr == 0) {
+            const cplx u = Yn[(size_t)j * ld + c];
+            Yn[(size_t)j * ld + c] = Yn[(size_t)p * ld + c];
+            Yn[(size_t)p * ld + c] = u;
+        }
+        __syncthreads();
+        const cplx yj = Yn[(size_t)j * ld + c];
+        const cplx* colj = AB + (size_t)j * ldab + kv;
+        for (int r = 1 + rr; r <= km; r += RL) {
+            cplx* y = Yn + (size_t)(j + r) * ld + c;
+            *y = csub(*y, cmul(colj[r], yj));
+        }
+        __syncthreads();
+    }
+    // backward: U x = y, U has kv super-diagonals
+    for (int j = N - 1; j >= 0; --j) {
+        const cplx* colj = AB + (size_t)j * ldab + kv;
+        if (rr == 0) Yn[(size_t)j * ld + c] = cdiv(Yn[(size_t)j * ld + c], colj[0]);
+        __syncthreads();
+        const cplx yj = Yn[(size_t)j * ld + c];
+        const int nr = min(kv, j);
+        for (int r = 1 + rr; r <= nr; r += RL) {
+            cplx* y = Yn + (size_t)(j - r) * ld + c;
+            *y = csub(*y, cmul(colj[-r], yj));
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------
+void fh_banded_free(feasthip_ctx* h) {
+    for (void* p : h->band_factors) if (p) hipFree(p);
+    for (int* p : h->band_pivots) if (p) hipFree(p);
+    h->band_factors.clear(); h->band_pivots.clear(); h->band_valid.clear(); h->band_z.clear();
+}
+
+static int band_check(feasthip_ctx* h) {
+    if (h->kind != 2) { h->last_error = "banded LU needs a CSR matrix (feasthip_set_csr)"; return FEASTHIP_ERROR_FPM; }
+    const int kl = h->csr_kl, ku = h->csr_ku;
+    const size_t lds = (size_t)(kl + kl + ku + 1) * sizeof(cplx);
+    if (lds > 60000) {
+        h->last_error = "banded LU: bandwidth too large (kl + (kl+ku) > ~3700); use an iterative solver";
+        return FEASTHIP_ERROR_FPM;
+    }
+    return 0;
+}
+
+static int band_ensure_slots(feasthip_ctx* h, int nslots) {
+    const size_t N = (size_t)h->csr.N, ldab = (size_t)2 * h->csr_kl + h->csr_ku + 1;
+    while ((int)h->band_factors.size() < nslots) {
+        void* f = nullptr; int* pv = nullptr;
+        if (hipMalloc(&f, ldab * N * sizeof(cplx)) != hipSuccess) { h->last_error = "hipMalloc(band factor)"; return FEASTHIP_ERROR_MEMORY; }
+        if (hipMalloc((void**)&pv, N * sizeof(int)) != hipSuccess) { hipFree(f); h->last_error = "hipMalloc(band pivots)"; return FEASTHIP_ERROR_MEMORY; }
+        h->band_factors.push_back(f); h->band_pivots.push_back(pv); h->band_valid.push_back(0); h->band_z.push_back(cmake(0, 0));
+    }
+    return 0;
+}
+
+static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const std::vector<cplx>& zlist, std::vector<int>& info_out) {
+    const int nf = (int)which.size();
+    info_out.assign(nf, 0);
+    if (nf == 0) return 0;
+    const int N = (int)h->csr.N, kl = h->csr_kl, ku = h->csr_ku;
+    const size_t ldab = (size_t)2 * kl + ku + 1;
+    void* p;
+    int rc;
+    std::vector<cplx*> abs(nf);
+    std::vector<int*> pvs(nf);
+    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)h->band_factors[which[q]]; pvs[q] = h->band_pivots[which[q]]; }
+    if ((rc = fh_get_buf(h, "bd_ptrs", nf * sizeof(cplx*), &p))) return rc;
+    cplx** dabs = (cplx**)p;
+    if ((rc = fh_get_buf(h, "bd_pptrs", nf * sizeof(int*), &p))) return rc;
+    int** dpvs = (int**)p;
+    if ((rc = fh_get_buf(h, "bd_z", nf * sizeof(cplx), &p))) return rc;
+    cplx* dz = (cplx*)p;
+    if ((rc = fh_get_buf(h, "bd_info", nf * sizeof(int), &p))) return rc;
+    int* dinfo = (int*)p;
+    FH_CHECK(hipMemcpyAsync(dabs, abs.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemsetAsync(dinfo, 0, nf * sizeof(int), h->stream));
+    for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(abs[q], 0, ldab * N * sizeof(cplx), h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    const dim3 grid((N + FH_BLOCK - 1) / FH_BLOCK, nf), block(FH_BLOCK);
+    const bool bid = h->csr.b_identity != 0;
+    fh_prof_begin(h, "band_form");
+    if (h->csr.is_complex) {
+        if (bid) hipLaunchKernelGGL((k_band_form<cplx, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)nullptr, dabs, dz, N, kl, ku);
+        else hipLaunchKernelGGL((k_band_form<cplx, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dabs, dz, N, kl, ku);
+    } else {
+        if (bid) hipLaunchKernelGGL((k_band_form<double, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)nullptr, dabs, dz, N, kl, ku);
+        else hipLaunchKernelGGL((k_band_form<double, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)h->csr.bval, dabs, dz, N, kl, ku);
+    }
+    fh_prof_end(h);
+    fh_prof_begin(h, "band_lu");
+    hipLaunchKernelGGL(k_band_lu, dim3(nf), dim3(BAND_THREADS), (size_t)(kl + kl + ku + 1) * sizeof(cplx), h->stream, dabs, dpvs, N, kl, ku, dinfo);
+    fh_prof_end(h);
+    FH_CHECK(hipMemcpyAsync(info_out.data(), dinfo, nf * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int band_solve_batch(feasthip_ctx* h, int ld, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
+    const int nf = (int)slots.size();
+    const int N = (int)h->csr.N;
+    void* p;
+    int rc;
+    std::vector<cplx*> abs(nf);
+    std::vector<int*> pvs(nf);
+    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)h->band_factors[slots[q]]; pvs[q] = h->band_pivots[slots[q]]; }
+    if ((rc = fh_get_buf(h, "bd_ptrs", nf * sizeof(cplx*), &p))) return rc;
+    cplx** dabs = (cplx**)p;
+    if ((rc = fh_get_buf(h, "bd_pptrs", nf * sizeof(int*), &p))) return rc;
+    int** dpvs = (int**)p;
+    FH_CHECK(hipMemcpyAsync(dabs, abs.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    fh_prof_begin(h, "band_solve");
+    const size_t total = (size_t)N * ld;
+    hipLaunchKernelGGL(k_band_copy_rhs, dim3((unsigned)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048), nf), dim3(FH_BLOCK), 0, h->stream, RHS, Y, stride, total);
+    hipLaunchKernelGGL(k_band_solve, dim3(ld / 16, nf), dim3(FH_BLOCK), 0, h->stream, dabs, dpvs, Y, stride, N, ld, h->csr_kl, h->csr_ku);
+    fh_prof_end(h);
+    return 0;
+}
+
+int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, cplx* Y,
+                          size_t stride, std::vector<int>& status, int64_t* nfact) {
+    (void)m;
+    int rc = band_check(h);
+    if (rc) return rc;
+    if ((rc = band_ensure_slots(h, nodes))) return rc;
+    std::vector<int> need;
+    std::vector<cplx> zl;
+    for (int e = 0; e < nodes; ++e) {
+        const bool ok = h->cache_factors && h->band_valid[e] == 1 && h->band_z[e].x == z[e].x && h->band_z[e].y == z[e].y;
+        if (!ok) { need.push_back(e); zl.push_back(z[e]); h->band_valid[e] = 0; }
+    }
+    std::vector<int> info;
+    if ((rc = band_factor_batch(h, need, zl, info))) return rc;
+    for (size_t q = 0; q < need.size(); ++q) {
+        h->band_z[need[q]] = zl[q];
+        h->band_valid[need[q]] = info[q] == 0 ? 1 : -1;
+    }
+    if (nfact) *nfact = (int64_t)need.size();
+    std::vector<int> slots(nodes);
+    for (int e = 0; e < nodes; ++e) slots[e] = e;
+    if ((rc = band_solve_batch(h, ld, slots, RHS, Y, stride))) return rc;
+    status.assign(nodes, 0);
+    for (int e = 0; e < nodes; ++e) if (h->band_valid[e] != 1) status[e] = FEASTHIP_ERROR_LAPACK;
+    return 0;
+}
+
+int fh_banded_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status, int64_t* nfact) {
+    (void)m;
+    int rc = band_check(h);
+    if (rc) return rc;
+    int slot = h->node_count;           // a shift equal to a local quadrature node reuses that node's factor
+    for (int e = 0; e < h->node_count && e < (int)h->node_ids.size(); ++e) {
+        const cplx ze = h->zne[h->node_ids[e]];
+        if (ze.x == z.x && ze.y == z.y) { slot = e; break; }
+    }
+    if ((rc = band_ensure_slots(h, std::max(slot, h->node_count) + 1))) return rc;
+    std::vector<int> need(1, slot), info;
+    std::vector<cplx> zl(1, z);
+    const bool cached = h->cache_factors && h->band_valid[slot] == 1 && h->band_z[slot].x == z.x && h->band_z[slot].y == z.y;
+    if (!cached) {
+        if ((rc = band_factor_batch(h, need, zl, info))) return rc;
+        h->band_z[slot] = z;
+        h->band_valid[slot] = info[0] == 0 ? 1 : -1;
+        if (nfact) *nfact = 1;
+    }
+    if ((rc = band_solve_batch(h, ld, need, RHS, Y, (size_t)h->csr.N * ld))) return rc;
+    *status = h->band_valid[slot] == 1 ? 0 : FEASTHIP_ERROR_LAPACK;
+    return 0;
+}

@@ -147,6 +147,12 @@ struct feasthip_ctx {
     std::vector<int*> lu_pivots;
     std::vector<int> lu_valid;
     std::vector<cplx> lu_z;
+    // banded LU (CSR input, FEASTHIP_SOLVER_BANDED): bandwidths of the union pattern, factors per node slot
+    int csr_kl = 0, csr_ku = 0;
+    std::vector<void*> band_factors;
+    std::vector<int*> band_pivots;
+    std::vector<int> band_valid;
+    std::vector<cplx> band_z;
     std::vector<int> col_mask;    // feasthip_set_column_mask: columns with 0 are not iterated by the Krylov solvers
     int sum_mode = 1;             // COCG contour_apply accumulates alpha*p into one shared panel (FH_NO_SUM_MODE=1 disables)
     int lu_outer_block = 128;     // FH_LU_KB: outer block column of the two-level LU (multiple of 32)

@@ -18,9 +18,10 @@ from . import _lib
 from ._lib import FeastHipStats, FeastHipUnavailable
 from .types import FeastHipError
 
-SOLVER_LU, SOLVER_BICGSTAB, SOLVER_GMRES, SOLVER_COCG = 0, 1, 2, 3
+SOLVER_LU, SOLVER_BICGSTAB, SOLVER_GMRES, SOLVER_COCG, SOLVER_BANDED = 0, 1, 2, 3, 4
 _SOLVER_CODES = {"direct": SOLVER_LU, "lu": SOLVER_LU, "bicgstab": SOLVER_BICGSTAB,
-                 "iterative": SOLVER_BICGSTAB, "gmres": SOLVER_GMRES, "cocg": SOLVER_COCG}
+                 "iterative": SOLVER_BICGSTAB, "gmres": SOLVER_GMRES, "cocg": SOLVER_COCG,
+                 "banded": SOLVER_BANDED}
 MAX_BLOCK = 64   # FH_MAX_LD: widest panel the kernels take in one call
 
 
@@ -146,7 +147,7 @@ class HipEngine:
     def set_solver(self, solver="direct", rtol=1e-12, atol=0.0, maxit=500, restart=30,
                    factor_precision=64, cache_factors=True):
         if solver not in _SOLVER_CODES:
-            raise ValueError(f"Unsupported solver option '{solver}'. Use :direct, :bicgstab, :gmres, or :iterative.")
+            raise ValueError(f"Unsupported solver option '{solver}'. Use :direct, :banded, :bicgstab, :cocg, :gmres, or :iterative.")
         self._chk(self.lib.feasthip_set_solver(self.h, _SOLVER_CODES[solver], float(rtol), float(atol), int(maxit),
                                                int(restart), int(factor_precision), int(bool(cache_factors))))
 

@@ -112,7 +112,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     if info:
         return FeastResult(np.zeros(0), np.zeros((N, 0), dtype=np.complex128), 0, np.zeros(0), info, math.inf, 0)
     rank, world = _world(group)
-    iterative = solver not in ("direct", "lu")
+    iterative = solver not in ("direct", "lu", "banded")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
 
     t_setup = time.perf_counter()
@@ -302,7 +302,7 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
     if not r > 0:
         return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 4, math.inf, 0)
     rank, world = _world(group)
-    iterative = solver not in ("direct", "lu")
+    iterative = solver not in ("direct", "lu", "banded")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
     Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
     Bc = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B) else B)
@@ -391,7 +391,7 @@ def feast_hip_complex_symmetric(engine, A, B, Emid, r, M0, fpm, *, solver="direc
         if not sym:                                          # check_complex_symmetric, feast_dense.jl:1038
             raise ValueError(f"Matrix {name} must be complex symmetric ({name} == transpose({name}))")
     rank_, world = _world(group)
-    iterative = solver not in ("direct", "lu")
+    iterative = solver not in ("direct", "lu", "banded")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
     Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
     Bc = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B) else B)

@@ -104,3 +104,43 @@ def julia_csc(A):
     M = sp.csc_matrix(A)
     M.sort_indices()
     return M.indptr.astype(np.int64) + 1, M.indices.astype(np.int64) + 1, np.ascontiguousarray(M.data)
+
+
+# ---- band storage of the reference's banded drivers (src/banded/feast_banded.jl:1-7, 205-271, 488-509)
+def band_upper_to_csr(Ab, k, kind="symmetric"):
+    """Upper band storage, (k+1) x N with A(i, j) = Ab[k + i - j, j] for i <= j (0-based), to a full
+    CSR matrix; the lower triangle is the mirror image: transposed ("symmetric",
+    "complex_symmetric") or conjugate-transposed ("hermitian")."""
+    Ab = np.asarray(Ab)
+    N = Ab.shape[1]
+    if Ab.shape[0] < k + 1:
+        raise ValueError("A matrix storage insufficient for k")
+    diags, offs = [Ab[k, :]], [0]
+    for d in range(1, k + 1):
+        up = Ab[k - d, d:]
+        diags += [up, np.conj(up) if kind == "hermitian" else up]
+        offs += [d, -d]
+    return sp.csr_matrix(sp.diags(diags, offs, shape=(N, N)))
+
+
+def band_general_to_csr(Ab, k):
+    """General band storage, (2k+1) x N with A(i, j) = Ab[k + i - j, j], |i - j| <= k."""
+    Ab = np.asarray(Ab)
+    N = Ab.shape[1]
+    diags, offs = [], []
+    for d in range(-k, k + 1):          # d = j - i
+        row = k - d
+        if 0 <= row < Ab.shape[0]:
+            diags.append(Ab[row, max(d, 0):N + min(d, 0)])
+            offs.append(d)
+    return sp.csr_matrix(sp.diags(diags, offs, shape=(N, N)))
+
+
+def csr_to_band_upper(A, k):
+    """Inverse of band_upper_to_csr (upper triangle only)."""
+    A = sp.csr_matrix(A)
+    N = A.shape[0]
+    Ab = np.zeros((k + 1, N), dtype=A.dtype)
+    for d in range(k + 1):
+        Ab[k - d, d:] = A.diagonal(d)
+    return Ab

@@ -56,6 +56,9 @@ enum {
                                       src/interfaces/feast_matfree.jl:716)                 */
     FEASTHIP_SOLVER_GMRES = 2,     /* :gmres   -- batched restarted GMRES(m)
                                       (src/sparse/feast_sparse.jl:183-188)                 */
+    FEASTHIP_SOLVER_BANDED = 4,    /* batched banded LU (ZGBTRF/ZGBTRS) for CSR input with a narrow band: the direct
+                                      solver of the banded drivers (src/banded/feast_banded.jl:100-150) and a
+                                      sparse direct path where the reference uses UMFPACK             */
     FEASTHIP_SOLVER_COCG = 3       /* conjugate-orthogonal CG for the complex-SYMMETRIC shifted
                                       systems that real-symmetric A, B produce (one operator
                                       application per iteration); not in the reference      */
