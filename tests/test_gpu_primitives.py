@@ -272,3 +272,27 @@ def test_gmres_shifted_solve(engine, N, m, restart, dense):
     xo, ok, _ = fo.gmres_restarted(mv, X[:, 0], 1e-10, 1e-10, 600, restart)
     assert ok and np.abs(xo - Y[:, 0]).max() <= 1e-7 * np.abs(xo).max()
     engine.set_solver("direct")
+
+
+@pytest.mark.parametrize("solver", ["cocg", "bicgstab"])
+def test_contour_apply_is_bitwise_reproducible(engine, solver):
+    """Two-stage fixed-order reductions and the in-order node sum of the COCG sum mode: the same call
+    twice gives the same bits (no float atomics)."""
+    import feastkit_jl_amd as fk
+    A, B, lam = fo.cfg3_problem(12, 10, 9)
+    N = A.shape[0]
+    engine.set_problem(A, B)
+    fpm = fk.feastdefault(fk.feastinit()); fpm[2] = 8
+    Z, W = fk.feast_contour(0.0, 0.5, fpm)
+    engine.set_contour(Z, W, 2.0)
+    engine.set_real_projection(True)
+    engine.set_solver(solver, rtol=1e-3, atol=0.0, maxit=60)
+    Q = engine.upload(fk.seeded_subspace(N, 24))
+    ritz = np.linspace(0.05, 0.9, 24)
+    outs = []
+    for _ in range(3):
+        dP, status, st = engine.contour_apply(Q, 24, ritz)
+        outs.append(engine.download(dP, 24).copy())
+    engine.set_real_projection(False)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
