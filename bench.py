@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--maxit", type=int, default=100)
     ap.add_argument("--solver", default="cocg", choices=["cocg", "bicgstab"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reduced-solver", default="host", choices=["host", "device"])
     ap.add_argument("--freeze-guards-after", type=int, default=-1,
                     help="loop index after which guard columns (Ritz value outside the interval) are no longer iterated; -1 = never")
     args = ap.parse_args()
@@ -111,7 +112,7 @@ def main():
         return fk.feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=args.solver, warm_start=True,
                                       inner_rtol=args.inner_rtol, solver_maxiter=args.maxit, preloaded=True,
                                       node_assignment="balanced", inner_precision=precision, column_groups="auto",
-                                      Q0=Q0_dev, real_projection=True,
+                                      Q0=Q0_dev, real_projection=True, reduced_solver=args.reduced_solver,
                                       freeze_guards_after=None if args.freeze_guards_after < 0 else args.freeze_guards_after)
 
     def fence():

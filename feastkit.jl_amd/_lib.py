@@ -42,6 +42,7 @@ SYMBOLS = {
     "feasthip_set_node_list": (_i, [_vp, _i, _vp]),
     "feasthip_set_solver": (_i, [_vp, _i, _d, _d, _i, _i, _i, _i]),
     "feasthip_set_column_mask": (_i, [_vp, _i64, _vp]),
+    "feasthip_rayleigh_ritz_dev": (_i, [_vp, _i64, _vp, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "feasthip_contour_apply": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
     "feasthip_contour_apply_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
     "feasthip_orthonormalize": (_i, [_vp, _i64, _vp, _d, _pi]),

@@ -4,6 +4,7 @@
 #include "fh_kernels.hpp"
 #include "fh_dense.hpp"
 #include "fh_banded.hpp"
+#include "fh_eig.hpp"
 #include "../../include/feasthip.h"
 
 #include <algorithm>
@@ -1765,6 +1766,70 @@ extern "C" int feasthip_ritz_residual(feasthip_handle h, int64_t r, const void* 
 // ---------------------------------------------------------------------------------------
 // RCI seams: Y = A X / B X (jobs 30/40), Y = (zB - A)^{-1} X (jobs 10+11, linear_solver)
 // ---------------------------------------------------------------------------------------
+// Rayleigh-Ritz step with the reduced eigenproblem on the device: project,
+// Jacobi eigensolver (fh_eig.hip) instead of host ZHEGV, stable inside-first reorder for [Emin, Emax]
+// (src/core/feast_aux.jl:144-197), X = Q V, normalise the inside columns, residuals.  The host sees
+// lambda[r] (reordered), M and res[M] only.  FEASTHIP_ERROR_LAPACK: the reduced B matrix is not
+// positive definite -- the caller falls back to project + host eigen + ritz_residual
+// (the general fallback of src/dense/feast_dense.jl:276-284).
+extern "C" int feasthip_rayleigh_ritz_dev(feasthip_handle h, int64_t r64, const void* dQ, double Emin, double Emax,
+                                          int use_B, void* dX, double* lambda_out, int* M_out, double* res_out) {
+    int rc = fh_check_problem(h, r64);
+    if (rc) return rc;
+    if (!dQ || !dX || !lambda_out || !M_out) { h->last_error = "rayleigh_ritz: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    const int r = (int)r64, ld = FH_MAX_LD;
+    std::vector<cplx> Sq((size_t)r * r), Aq((size_t)r * r);
+    if ((rc = feasthip_project_dev(h, r64, dQ, 0, 1, Sq.data(), Aq.data()))) return rc;
+    bool a_identity = fh_b_identity(h) != 0;                 // project returned exactly I
+    void* p;
+    if ((rc = fh_get_buf(h, "rr_S", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* dS = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rr_A", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* dA = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rr_V", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* dV = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rr_lam", ld * sizeof(double), &p))) return rc;
+    double* dlam = (double*)p;
+    if ((rc = fh_get_buf(h, "rr_flags", 4 * sizeof(int), &p))) return rc;
+    int* dflags = (int*)p;
+    if ((rc = fh_get_buf(h, "rr_scratch", fh_herm_eig_scratch_bytes(), &p))) return rc;
+    void* scratch = p;
+    std::vector<cplx> pad((size_t)ld * ld, cmake(0, 0));
+    for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) pad[(size_t)j * ld + i] = Sq[(size_t)j * r + i];
+    FH_CHECK(hipMemcpyAsync(dS, pad.data(), pad.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (!a_identity) {
+        for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) pad[(size_t)j * ld + i] = Aq[(size_t)j * r + i];
+        FH_CHECK(hipMemcpyAsync(dA, pad.data(), pad.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+    }
+    fh_prof_begin(h, "reduced_eig");
+    fh_launch_herm_eig(r, ld, dS, a_identity ? nullptr : dA, scratch, dlam, dV, dflags, h->stream);
+    fh_prof_end(h);
+    std::vector<double> lam(r);
+    std::vector<cplx> V((size_t)ld * ld);
+    int flags[4];
+    FH_CHECK(hipMemcpyAsync(flags, dflags, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipMemcpyAsync(lam.data(), dlam, r * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipMemcpyAsync(V.data(), dV, V.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (flags[0] || flags[2]) { h->last_error = "rayleigh_ritz: reduced B matrix not positive definite"; return FEASTHIP_ERROR_LAPACK; }
+    // stable inside-first permutation
+    std::vector<int> perm;
+    for (int i = 0; i < r; ++i) if (lam[i] >= Emin && lam[i] <= Emax) perm.push_back(i);
+    const int M = (int)perm.size();
+    for (int i = 0; i < r; ++i) if (!(lam[i] >= Emin && lam[i] <= Emax)) perm.push_back(i);
+    std::vector<cplx> Vs((size_t)r * r);
+    std::vector<double> lamc(2 * (size_t)r);
+    for (int k = 0; k < r; ++k) {
+        lambda_out[k] = lam[perm[k]];
+        lamc[2 * k] = lam[perm[k]]; lamc[2 * k + 1] = 0.0;
+        for (int i = 0; i < r; ++i) Vs[(size_t)k * r + i] = V[(size_t)perm[k] * ld + i];
+    }
+    *M_out = M;
+    return feasthip_ritz_residual_dev(h, r64, dQ, Vs.data(), lamc.data(), M, 1, use_B, dX, res_out);
+}
+
 extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, const void* dX, void* dY) {
     if (m64 > FH_MAX_LD) {          // independent columns: 64 at a time
         int rc0 = fh_check_problem(h, m64, 1);

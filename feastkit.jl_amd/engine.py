@@ -241,6 +241,22 @@ class HipEngine:
                                                       _np_ptr(res)))
         return dX, res[:M].copy()
 
+    def rayleigh_ritz(self, dQ, r, Emin, Emax, use_B=True):
+        """Project, solve the reduced Hermitian-definite pencil ON THE DEVICE (Jacobi), reorder inside-first,
+        back-transform and measure residuals in one call.  Returns (dX, lambda[r], M, res[M]), or None when
+        the reduced B matrix is not positive definite (caller falls back to the host eigensolver)."""
+        self._sync_stream()
+        dX = self.empty(dQ.shape[0])
+        lam = np.zeros(r, dtype=np.float64)
+        res = np.zeros(r, dtype=np.float64)
+        M = C.c_int(0)
+        rc = self.lib.feasthip_rayleigh_ritz_dev(self.h, r, C.c_void_p(dQ.data_ptr()), float(Emin), float(Emax), int(bool(use_B)),
+                                                 C.c_void_p(dX.data_ptr()), _np_ptr(lam), C.byref(M), _np_ptr(res))
+        if rc == 8:
+            return None
+        self._chk(rc)
+        return dX, lam, int(M.value), res[:int(M.value)]
+
     def matmul(self, which, dX, m):
         self._sync_stream()
         dY = self.empty(dX.shape[0])

@@ -32,6 +32,30 @@ from .types import FeastError, FeastResult
 
 SQRT_EPS = math.sqrt(np.finfo(np.float64).eps)
 
+try:
+    # The reduced M0 x M0 problems are far too small for threaded BLAS, and a BLAS pool that keeps spinning
+    # after the call starves the thread that feeds the GPU launch queue (measured on a 256-core host:
+    # 0.89 s -> 0.71 s per cfg-3 solve).
+    from threadpoolctl import ThreadpoolController as _ThreadpoolController
+    _BLAS_POOLS = _ThreadpoolController()
+except Exception:
+    _BLAS_POOLS = None
+
+
+class small_lapack:
+    """Context manager: run the enclosed host LAPACK calls on one BLAS thread."""
+
+    def __enter__(self):
+        self._ctx = _BLAS_POOLS.limit(limits=1) if _BLAS_POOLS is not None else None
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
 
 def seeded_subspace(N, M0, seed=20260515, complex_values=False):
     """Initial subspace: real Gaussian columns of unit norm (src/core/feast_tools.jl:6-43).
@@ -66,15 +90,17 @@ def _reorder_by_interval(lam, Emin, Emax, n):
 def _reduced_hermitian_eig(Sq, Aq):
     """eigen(Hermitian(Sq), Hermitian(Aq)) with the general fallback
     (src/dense/feast_dense.jl:270-284)."""
-    try:
-        lam, V = sla.eigh(Sq, Aq)
-        return np.asarray(lam, dtype=np.float64), V
-    except Exception:
-        w, V = sla.eig(Sq, Aq)
-        return np.real(w).astype(np.float64), V
+    with small_lapack():
+        try:
+            lam, V = sla.eigh(Sq, Aq)
+            return np.asarray(lam, dtype=np.float64), V
+        except Exception:
+            w, V = sla.eig(Sq, Aq)
+            return np.real(w).astype(np.float64), V
 
 
-def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_after=None, solver="direct", solver_tol=0.0,
+def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_after=None, reduced_solver="host",
+                        solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
                         preloaded=False, node_assignment="block", inner_precision=64, column_groups=1):
@@ -239,6 +265,35 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         if rank_q == 0:
             info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
             break
+        if reduced_solver == "device" and rank_q <= 64 and trace is None and hasattr(engine, "rayleigh_ritz"):
+            # project + reduced eigenproblem (Jacobi in LDS) + reorder + Ritz vectors + residuals in one call;
+            # None: reduced B not positive definite -> the host path below (general fallback of the reference)
+            t_ = tick()
+            rr = engine.rayleigh_ritz(dP, rank_q, Emin, Emax, use_B=True)
+            ph["ritz"] += tick() - t_
+            if rr is not None:
+                dX, lam_sorted, M, res = rr
+                if M == 0 and not (iterative and warm_start):
+                    info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                    break
+                lam_vec[:rank_q] = lam_sorted
+                if M > 0:
+                    res_vec[:M] = res
+                    epsout = float(res.max())
+                else:
+                    epsout = math.inf
+                M_found = M
+                stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout,
+                                       "krylov_iterations": st.get("krylov_iterations", 0)})
+                if M > 0 and epsout <= eps_tol:
+                    break
+                if loop_idx == maxloop:
+                    info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                    break
+                active = rank_q
+                dQ = dX
+                ritz_lambda = lam_sorted.copy()
+                continue
         t_ = tick()
         Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
         ph["project"] += tick() - t_
@@ -339,7 +394,8 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
                                math.inf, loop, stats)
         Aq, Sq = engine.project(dq, M0, bilinear=False, hermitize=False)   # Aq = q^H A q, Sq = q^H B q
         try:
-            lam_red, v_red = sla.eig(Aq, Sq)                                # feast_kernel.jl:812
+            with small_lapack():
+                lam_red, v_red = sla.eig(Aq, Sq)                            # feast_kernel.jl:812
         except Exception:
             return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0),
                                int(FeastError.Feast_ERROR_LAPACK), math.inf, loop, stats)
@@ -434,7 +490,8 @@ def feast_hip_complex_symmetric(engine, A, B, Emid, r, M0, fpm, *, solver="direc
             break
         Ared, Bred = engine.project(dP, rank_q, bilinear=True, hermitize=False)   # q^T A q, q^T B q
         try:
-            lam_red, v_red = sla.eig(Ared, Bred)
+            with small_lapack():
+                lam_red, v_red = sla.eig(Ared, Bred)
         except Exception:
             info = int(FeastError.Feast_ERROR_LAPACK)
             break
@@ -517,9 +574,11 @@ def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None
         try:
             Su = np.triu(Sq) + np.triu(Sq, 1).T               # Symmetric(X) reads the upper triangle
             Au = np.triu(Aq) + np.triu(Aq, 1).T
-            lam_red, v_red = sla.eigh(Su, Au)
+            with small_lapack():
+                lam_red, v_red = sla.eigh(Su, Au)
         except Exception:
-            w_, v_red = sla.eig(Sq, Aq)
+            with small_lapack():
+                w_, v_red = sla.eig(Sq, Aq)
             lam_red, v_red = np.real(w_), np.real(v_red)
         q = Q_proj @ v_red
         perm, M = _reorder_by_interval(lam_red, Emin, Emax, M0)

@@ -32,6 +32,18 @@ from .contour import feast_contour, feast_gcontour, feast_inside_gcontour
 from .parameters import feast_tolerance, feastdefault
 from .types import FeastError, FeastRCIJob, FeastResult
 
+
+class small_lapack:
+    """One BLAS thread for the tiny reduced eigenproblems (see hip_backend.small_lapack)."""
+
+    def __enter__(self):
+        from .hip_backend import small_lapack as _sl
+        self._c = _sl()
+        return self._c.__enter__()
+
+    def __exit__(self, *exc):
+        return self._c.__exit__(*exc)
+
 JOB_INIT = int(FeastRCIJob.Feast_RCI_INIT)
 JOB_DONE = int(FeastRCIJob.Feast_RCI_DONE)
 JOB_FACTORIZE = int(FeastRCIJob.Feast_RCI_FACTORIZE)
@@ -200,7 +212,8 @@ def feast_srci(refs, N, work, workc, Aq, Sq, fpm, Emin, Emax, M0, lambda_, q, re
         Aq[:Mc, :Mc] = state.zAq[:Mc, :Mc].real
         Sq[:Mc, :Mc] = state.zSq[:Mc, :Mc].real
         try:
-            w, V = sla.eig(Sq[:Mc, :Mc], Aq[:Mc, :Mc])
+            with small_lapack():
+                w, V = sla.eig(Sq[:Mc, :Mc], Aq[:Mc, :Mc])
             V = _lapack_scaling(V)
             lam = np.real(w)
             Aq[:Mc, :Mc] = np.real(V)
@@ -310,7 +323,8 @@ def feast_hrci(refs, N, work, workc, zAq, zSq, fpm, Emin, Emax, M0, lambda_, q, 
             return
         state.e = 1
         try:
-            w, V = sla.eig(zSq[:Mc, :Mc], zAq[:Mc, :Mc])
+            with small_lapack():
+                w, V = sla.eig(zSq[:Mc, :Mc], zAq[:Mc, :Mc])
             V = _lapack_scaling(V)
             lam = np.real(w)
             q[:, :Mc] = state.Q_proj[:, :Mc] @ V
@@ -422,7 +436,8 @@ def feast_grci(refs, N, work, workc, Aq, Sq, fpm, Emid, r, M0, lambda_, q, res, 
             Aq[:M0, :M0] = q[:, :M0].conj().T @ workc[:, :M0]
             state.mult_a_for_projection = False
             try:
-                w, V = sla.eig(Aq, Sq)
+                with small_lapack():
+                    w, V = sla.eig(Aq, Sq)
                 V = _lapack_scaling(V)
                 flags = [feast_inside_gcontour(w[i], Emid, r, fpm) for i in range(M0)]
                 perm, M = _inside_first(flags)

@@ -201,6 +201,16 @@ int  feasthip_ritz_residual_dev(feasthip_handle h, int64_t r, const void* dQ, co
                                 void* dX, double* res_host);
 
 /* ---- RCI / matrix-free seams -------------------------------------- */
+/* Rayleigh-Ritz step with the reduced eigenproblem on the device:
+ * feasthip_project, then the Hermitian-definite r x r pencil is solved by a Jacobi eigensolver in LDS
+ * (instead of eigen(Hermitian(Sq), Hermitian(Aq)), src/dense/feast_dense.jl:272), stable inside-first
+ * reorder for [Emin, Emax] (src/core/feast_aux.jl:144-197), then feasthip_ritz_residual.  r <= 64.
+ * Out: X (N x r device), lambda[r] (reordered, inside first), *M, res[M].  Returns 8 when the reduced
+ * B matrix is not positive definite (use project + a host general eigensolver + ritz_residual then,
+ * the fallback of src/dense/feast_dense.jl:276-284).                                            */
+int  feasthip_rayleigh_ritz_dev(feasthip_handle h, int64_t r, const void* dQ, double Emin, double Emax,
+                                int use_B, void* dX, double* lambda_out, int* M_out, double* res_out);
+
 /* Y = op * X for op = A (which=0) or B (which=1): RCI jobs 30 / 40
  * (src/core/feast_types.jl:227-249; callers src/dense/feast_dense.jl:561-573).          */
 int  feasthip_matmul(feasthip_handle h, int which, int64_t m, const void* X, void* Y);

@@ -196,7 +196,13 @@ def test_cfg3_reduced_reference_mode_and_fast_mode(engine):
     fpm = fpm_with(f2=8, f4=40)
     frozen = fk.feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, solver="cocg", warm_start=True, inner_rtol=1e-2,
                                     solver_maxiter=100, real_projection=True, freeze_guards_after=2)
-    for r in (strict, fast, mixed, frozen):
+    # reduced eigenproblem on the device (Jacobi) instead of host LAPACK: same answer, same loop count
+    devrr = fk.feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm_with(f2=8, f4=40), solver="cocg", warm_start=True,
+                                   inner_rtol=1e-2, solver_maxiter=100, real_projection=True, reduced_solver="device")
+    hostrr = fk.feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm_with(f2=8, f4=40), solver="cocg", warm_start=True,
+                                    inner_rtol=1e-2, solver_maxiter=100, real_projection=True)
+    assert abs(devrr.loop - hostrr.loop) <= 1
+    for r in (strict, fast, mixed, frozen, devrr):
         assert r.info == 0 and r.M == len(inside) == ref.M
         assert np.allclose(np.sort(r.lambda_), inside, atol=1e-10)
         assert np.allclose(np.sort(r.lambda_), np.sort(ref.lam), atol=1e-10)

@@ -296,3 +296,46 @@ def test_contour_apply_is_bitwise_reproducible(engine, solver):
     engine.set_real_projection(False)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
     assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+
+
+@pytest.mark.parametrize("N,r,generalized,cplx", [(60, 5, False, False), (300, 17, True, False), (800, 32, True, True),
+                                                 (1500, 64, True, False), (700, 63, False, True)])
+def test_rayleigh_ritz_on_device_matches_host_path(engine, N, r, generalized, cplx):
+    """feasthip_rayleigh_ritz_dev (Jacobi eigensolver in LDS) against project + LAPACK zhegv + ritz_residual."""
+    A, B = sparse_pair(N, 31, cplx=cplx, b_identity=not generalized)
+    engine.set_problem(A, B)
+    Q = rand_block(N, r, 4, cplx=cplx)
+    dQ = engine.upload(Q)
+    rank = engine.orthonormalize(dQ, r, 1e-8)
+    assert rank == r
+    Sq, Aq = engine.project(dQ, r, bilinear=False, hermitize=True)
+    lam_ref, V = sla.eigh(Sq, Aq)
+    lo, hi = lam_ref[r // 4] - 1e-9, lam_ref[(3 * r) // 4] + 1e-9
+    inside = [i for i in range(r) if lo <= lam_ref[i] <= hi]
+    perm = inside + [i for i in range(r) if i not in set(inside)]
+    dXh, res_h = engine.ritz_residual(dQ, r, np.asfortranarray(V[:, perm]), lam_ref[perm], len(inside), normalize=True, use_B=True)
+    out = engine.rayleigh_ritz(dQ, r, lo, hi, use_B=True)
+    assert out is not None
+    dX, lam, M, res = out
+    scale = np.abs(lam_ref).max()
+    assert M == len(inside)
+    assert np.abs(lam - lam_ref[perm]).max() <= 1e-13 * scale
+    assert np.abs(res - res_h).max() <= 1e-9 * max(res_h.max(), 1e-300) + 1e-13
+    # same Ritz vectors up to a unit phase per column (eigenvalues are simple here)
+    Xd, Xh = engine.download(dX)[:, :M], engine.download(dXh)[:, :M]
+    for j in range(M):
+        ph = np.vdot(Xh[:, j], Xd[:, j])
+        assert abs(abs(ph) - 1.0) <= 1e-9
+        assert np.linalg.norm(Xd[:, j] - ph * Xh[:, j]) <= 1e-8
+    if not cplx:
+        assert np.abs(engine.download(dX).imag).max() <= 1e-14 * np.abs(engine.download(dX)).max()   # real input stays real
+
+
+def test_rayleigh_ritz_reports_indefinite_b(engine):
+    N = 50
+    A = sp.csr_matrix(sp.diags([np.arange(1.0, N + 1)], [0]))
+    B = sp.csr_matrix(sp.diags([np.where(np.arange(N) % 2 == 0, 1.0, -1.0)], [0]))    # indefinite "B"
+    engine.set_problem(A, B)
+    dQ = engine.upload(rand_block(N, 6, 1, cplx=False))
+    assert engine.orthonormalize(dQ, 6, 1e-8) == 6
+    assert engine.rayleigh_ritz(dQ, 6, 0.0, 10.0) is None
