@@ -84,7 +84,8 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
 
 
 def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend="hip", solver="direct",
-                  solver_tol=0.0, solver_maxiter=500, solver_restart=30, group=None, engine=None, device=0, Q0=None):
+                  solver_tol=0.0, solver_maxiter=500, solver_restart=30, group=None, engine=None, device=0, Q0=None,
+                  inner_precision=64):
     """feast_general(A, [B,] center, radius; M0, fpm): src/interfaces/feast_interfaces.jl:274-379."""
     if backend not in _BACKENDS:
         raise ValueError(f"Unknown backend '{backend}' (this package provides: hip)")
@@ -98,6 +99,6 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
     if sp.issparse(A) and solver in ("direct", "lu"):
         solver = _sparse_direct_solver(A, B, int(fpm[8]))
     eng = _engine(engine, device)
-    return feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver,
+    return feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver, inner_precision=inner_precision,
                              solver_tol=solver_tol, solver_maxiter=solver_maxiter,
                              solver_restart=solver_restart, group=group, Q0=Q0)

@@ -886,6 +886,72 @@ static bool fh_is_complex_input(feasthip_ctx* h) { return h->kind == 2 ? h->csr.
 // ---------------------------------------------------------------------------------------
 // contour sweep
 // ---------------------------------------------------------------------------------------
+// Mixed-precision dense solves (factor_precision = 32): complex64 LU factors, fp64 iterative refinement
+//     Y <- Y + LU32^-1 (RHS - (z_e B - A) Y)
+// until the relative residual of every column is below max(rtol, 1e-14) (rtol of feasthip_set_solver; a
+// value >= 1 means no refinement at all: plain complex64 solves for the early, inexact FEAST loops), or
+// stops improving; at most 8 steps.
+// The residual is the fp64 dense operator kernel, so the result has fp64 accuracy as long as
+// cond(z_e B - A) * eps32 < 1.  `single`: one shift through fh_dense_lu_solve_single (nodes == 1).
+static int fh_dense_lu_refined(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* Rhs, cplx* Y,
+                               size_t panel, std::vector<int>& status, int64_t* nfact, bool single, double* worst_out) {
+    const int N = (int)fh_N(h);
+    int rc;
+    void* p;
+    auto solve = [&](const cplx* rhs, size_t rhs_stride, cplx* out, int64_t* nf) -> int {
+        if (single) return fh_dense_lu_solve_single(h, ld, m, z[0], rhs, out, &status[0], nf);
+        return fh_dense_lu_solve_nodes(h, ld, m, nodes, z, rhs, rhs_stride, out, panel, status, nf);
+    };
+    if ((rc = solve(Rhs, 0, Y, nfact))) return rc;
+    const double tol = std::max(h->rtol, 1e-14);
+    if (tol >= 1.0) { if (worst_out) *worst_out = 0.0; return 0; }
+    if ((rc = fh_get_buf(h, "lr_R", (size_t)nodes * panel * sizeof(cplx), &p))) return rc;
+    cplx* R = (cplx*)p;
+    if ((rc = fh_get_buf(h, "lr_D", (size_t)nodes * panel * sizeof(cplx), &p))) return rc;
+    cplx* D = (cplx*)p;
+    if ((rc = fh_get_buf(h, "lr_part", (size_t)fh_vec_nblk(N, ld) * ld * sizeof(cplx), &p))) return rc;
+    cplx* part = (cplx*)p;
+    if ((rc = fh_get_buf(h, "lr_dots", (size_t)(nodes + 1) * ld * sizeof(cplx), &p))) return rc;
+    cplx* ddots = (cplx*)p;
+    const size_t nl = (size_t)nodes * ld;
+    std::vector<cplx> ca(nl, cmake(-1, 0)), cb(nl), mone(ld, cmake(-1, 0));
+    for (int e = 0; e < nodes; ++e) for (int c = 0; c < ld; ++c) cb[(size_t)e * ld + c] = z[e];
+    cplx *dca, *dcb, *dmone;
+    if ((rc = fh_upload_coefs(h, "lr_coefA", ca, &dca))) return rc;
+    if ((rc = fh_upload_coefs(h, "lr_coefB", cb, &dcb))) return rc;
+    if ((rc = fh_upload_coefs(h, "lr_mone", mone, &dmone))) return rc;
+    std::vector<cplx> dots((size_t)(nodes + 1) * ld);
+    fh_launch_dot_cols(Rhs, Rhs, N, ld, part, ddots + (size_t)nodes * ld, h->stream);
+    double prev = 1e300, worst = 0.0;
+    for (int it = 0; it < 8; ++it) {
+        fh_op_call oc;
+        oc.m = m; oc.uniform_coef = 1; oc.prec = 64;
+        oc.X = Y; oc.x_stride = panel; oc.Y = R; oc.y_stride = panel; oc.coefA = dca; oc.coefB = dcb;
+        oc.Bvec = Rhs; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+        oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = nodes;
+        fh_apply_operator(h, ld, oc);                               // R = RHS - S Y
+        for (int e = 0; e < nodes; ++e)
+            fh_launch_dot_cols(R + (size_t)e * panel, R + (size_t)e * panel, N, ld, part, ddots + (size_t)e * ld, h->stream);
+        FH_CHECK(hipMemcpyAsync(dots.data(), ddots, dots.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        worst = 0.0;
+        for (int e = 0; e < nodes; ++e) {
+            if (status[e]) continue;                                 // singular factor: reported, not refined
+            for (int c = 0; c < m; ++c) {
+                const double b2 = dots[(size_t)nodes * ld + c].x, r2 = dots[(size_t)e * ld + c].x;
+                if (b2 > 0.0) worst = std::max(worst, std::sqrt(r2 / b2));
+            }
+        }
+        if (!(worst > tol) || !(worst < 0.5 * prev) || !std::isfinite(worst)) break;
+        prev = worst;
+        if ((rc = solve(R, panel, D, nullptr))) return rc;          // D = LU32^-1 R
+        for (int e = 0; e < nodes; ++e)
+            fh_launch_axpy_cols(Y + (size_t)e * panel, D + (size_t)e * panel, dmone, N, ld, h->stream);   // Y += D
+    }
+    if (worst_out) *worst_out = worst;
+    return 0;
+}
+
 static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
                                   cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
     int rc = fh_check_problem(h, m64);
@@ -943,9 +1009,11 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     if (h->solver == FEASTHIP_SOLVER_LU) {
         if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix (sparse direct factorisation is not provided; use BICGSTAB)"; return FEASTHIP_ERROR_FPM; }
         int64_t nfact = 0;
-        rc = fh_dense_lu_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
+        double worst = 0.0;
+        if (h->factor_precision == 32) rc = fh_dense_lu_refined(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact, false, &worst);
+        else rc = fh_dense_lu_solve_nodes(h, ld, m, nodes, z, Rhs, 0, Y, panel, status, &nfact);
         if (rc) return rc;
-        if (stats) stats->factorizations = nfact;
+        if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         int64_t nfact = 0;
         rc = fh_banded_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
@@ -1927,9 +1995,11 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix"; return FEASTHIP_ERROR_FPM; }
         int64_t nfact = 0;
         // cached per quadrature node when z is one, else in one extra slot
-        rc = fh_dense_lu_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
+        double worst = 0.0;
+        if (h->factor_precision == 32) rc = fh_dense_lu_refined(h, ld, m, 1, z, Rhs, Y, panel, status, &nfact, true, &worst);
+        else rc = fh_dense_lu_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;
-        if (stats) stats->factorizations = nfact;
+        if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         int64_t nfact = 0;
         rc = fh_banded_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);

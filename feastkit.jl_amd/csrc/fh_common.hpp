@@ -147,6 +147,7 @@ struct feasthip_ctx {
     std::vector<int*> lu_pivots;
     std::vector<int> lu_valid;
     std::vector<cplx> lu_z;
+    int lu_prec = 64;             // element type of the cached dense factors: 64 = complex128, 32 = complex64
     // banded LU (CSR input, FEASTHIP_SOLVER_BANDED): bandwidths of the union pattern, factors per node slot
     int csr_kl = 0, csr_ku = 0;
     std::vector<void*> band_factors;

@@ -148,12 +148,34 @@ void fh_launch_axpy_cols(cplx* R, const cplx* X, const cplx* lam, int N, int ld,
 }
 
 // ---------------------------------------------------------------------------------------
-// batched LU
+// batched LU -- templated on the factor element type T: cplx (complex128) or cplxf (complex64,
+// factor_precision = 32: factors and triangular solves in single precision inside an fp64
+// iterative-refinement loop, fh_api.hip).  The f32 and f64 16x16x4 MFMA differ in the C/D row map.
 // ---------------------------------------------------------------------------------------
-template <typename VT, bool BIDENT>
+typedef double lu_v4d __attribute__((ext_vector_type(4)));
+typedef float lu_v4f __attribute__((ext_vector_type(4)));
+__host__ __device__ inline cplxf cdiv(cplxf a, cplxf b) {
+    float d = b.x * b.x + b.y * b.y;
+    return cmakef((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+template <typename T> struct lu_el;
+template <> struct lu_el<cplx> {
+    typedef lu_v4d v4;
+    __host__ __device__ static cplx mk(double a, double b) { return cmake(a, b); }
+    __device__ static int mrow(int lk, int r) { return lk + 4 * r; }
+    __device__ static v4 mfma(double a, double b, v4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
+template <> struct lu_el<cplxf> {
+    typedef lu_v4f v4;
+    __host__ __device__ static cplxf mk(double a, double b) { return cmakef((float)a, (float)b); }
+    __device__ static int mrow(int lk, int r) { return 4 * lk + r; }
+    __device__ static v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+#define LU_MK(a, b) lu_el<T>::mk((a), (b))
+template <typename VT, bool BIDENT, typename T>
 __global__ __launch_bounds__(FH_BLOCK) void k_form_shifted(const VT* __restrict__ A, const VT* __restrict__ B,
-                                                            cplx* const* LUs, const cplx* z, int N) {
-    cplx* S = LUs[blockIdx.y];
+                                                            T* const* LUs, const cplx* z, int N) {
+    T* S = LUs[blockIdx.y];
     const cplx zz = z[blockIdx.y];
     const size_t total = (size_t)N * N;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
@@ -166,15 +188,16 @@ __global__ __launch_bounds__(FH_BLOCK) void k_form_shifted(const VT* __restrict_
             if constexpr (sizeof(VT) == sizeof(cplx)) b = cmake(B[e].x, B[e].y); else b = cmake(B[e], 0.0);
             cfma(v, zz, b);
         }
-        S[e] = v;
+        S[e] = cvt<T>(v);
     }
 }
 
 // Panel factorisation: one workgroup per matrix walks the nb panel columns; pivot rule is
 // LAPACK's IZAMAX (max |re|+|im|, lowest index on ties).
-__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(cplx* const* LUs, int* const* pivs, int N, int k0,
+template <typename T>
+__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(T* const* LUs, int* const* pivs, int N, int k0,
                                                                 int nb, int* info) {
-    cplx* A = LUs[blockIdx.x];
+    T* A = LUs[blockIdx.x];
     int* piv = pivs[blockIdx.x];
     __shared__ double smax[LU_PANEL_THREADS];
     __shared__ int sidx[LU_PANEL_THREADS];
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(cplx* const* LUs,
         double best = -1.0;
         int bi = jj;
         for (int i = jj + t; i < N; i += LU_PANEL_THREADS) {
-            cplx v = A[(size_t)jj * N + i];
+            T v = A[(size_t)jj * N + i];
             double m = fabs(v.x) + fabs(v.y);
             if (m > best) { best = m; bi = i; }
         }
@@ -206,21 +229,21 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(cplx* const* LUs,
         __syncthreads();
         const int p = sp;
         if (t < nb && p != jj) {
-            cplx u = A[(size_t)(k0 + t) * N + jj];
+            T u = A[(size_t)(k0 + t) * N + jj];
             A[(size_t)(k0 + t) * N + jj] = A[(size_t)(k0 + t) * N + p];
             A[(size_t)(k0 + t) * N + p] = u;
         }
         __syncthreads();
-        const cplx pv = A[(size_t)jj * N + jj];
+        const T pv = A[(size_t)jj * N + jj];
         const bool singular = (pv.x == 0.0 && pv.y == 0.0);
-        const cplx inv = singular ? cmake(0, 0) : cdiv(cmake(1, 0), pv);
+        const T inv = singular ? LU_MK(0, 0) : cdiv(LU_MK(1, 0), pv);
         for (int i = jj + 1 + t; i < N; i += LU_PANEL_THREADS) A[(size_t)jj * N + i] = cmul(A[(size_t)jj * N + i], inv);
         __syncthreads();
         const int ncols = k0 + nb - 1 - jj, nrows = N - 1 - jj;
         for (int e = t; e < nrows * ncols; e += LU_PANEL_THREADS) {
             int i = jj + 1 + e % nrows, c = jj + 1 + e / nrows;
-            cplx l = A[(size_t)jj * N + i], u = A[(size_t)c * N + jj];
-            cplx v = A[(size_t)c * N + i];
+            T l = A[(size_t)jj * N + i], u = A[(size_t)c * N + jj];
+            T v = A[(size_t)c * N + i];
             A[(size_t)c * N + i] = csub(v, cmul(l, u));
         }
         __syncthreads();
@@ -240,16 +263,16 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(cplx* const* LUs,
 //      except the row interchange of the other panel columns.
 // Pivot rule as k_lu_panel (LAPACK IZAMAX).  Each panel entry is read from and written to
 // global memory once per sub-panel it participates in, instead of once per column.
-template <int R, int W>
-__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* LUs, int* const* pivs, int N, int k0,
+template <int R, int W, typename T>
+__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs, int* const* pivs, int N, int k0,
                                                                     int nb, int* info) {
-    cplx* A = LUs[blockIdx.x];
+    T* A = LUs[blockIdx.x];
     int* piv = pivs[blockIdx.x];
     __shared__ double wmax[LU_PANEL_THREADS / 64];
     __shared__ int widx[LU_PANEL_THREADS / 64];
-    __shared__ cplx rowA[W], rowB[W];
-    __shared__ cplx Lsm[LU_NB][LU_NB + 1];
-    __shared__ cplx Us[LU_NB][W];
+    __shared__ T rowA[W], rowB[W];
+    __shared__ T Lsm[LU_NB][LU_NB + 1];
+    __shared__ T Us[LU_NB][W];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int kend = k0 + nb;
     int rows[R];
@@ -272,7 +295,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* 
             __syncthreads();
             if (t < wact) {
                 for (int i = 1; i < pc; ++i) {
-                    cplx x = Us[i][t];
+                    T x = Us[i][t];
                     for (int j = 0; j < i; ++j) x = csub(x, cmul(Lsm[i][j], Us[j][t]));
                     Us[i][t] = x;
                 }
@@ -281,17 +304,17 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* 
             __syncthreads();
         }
         // ---- 2. load owned rows (>= c0) and apply the previous columns
-        cplx a[R][W];
+        T a[R][W];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int w = 0; w < W; ++w)
-                a[r][w] = (rows[r] >= c0 && rows[r] < N && w < wact) ? A[(size_t)(c0 + w) * N + rows[r]] : cmake(0, 0);
+                a[r][w] = (rows[r] >= c0 && rows[r] < N && w < wact) ? A[(size_t)(c0 + w) * N + rows[r]] : LU_MK(0, 0);
         for (int p = 0; p < pc; ++p) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (rows[r] >= c0 && rows[r] < N) {
-                    const cplx l = A[(size_t)(k0 + p) * N + rows[r]];
+                    const T l = A[(size_t)(k0 + p) * N + rows[r]];
 #pragma unroll
                     for (int w = 0; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, Us[p][w]));
                 }
@@ -344,14 +367,14 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* 
                 }
                 // the panel columns outside this sub-panel: interchange in global memory
                 if (p != jj && t < nb && (k0 + t < c0 || k0 + t >= c0 + W)) {
-                    cplx u = A[(size_t)(k0 + t) * N + jj];
+                    T u = A[(size_t)(k0 + t) * N + jj];
                     A[(size_t)(k0 + t) * N + jj] = A[(size_t)(k0 + t) * N + p];
                     A[(size_t)(k0 + t) * N + p] = u;
                 }
                 __syncthreads();
-                const cplx pv = rowB[j];
+                const T pv = rowB[j];
                 const bool singular = (pv.x == 0.0 && pv.y == 0.0);
-                const cplx inv = singular ? cmake(0, 0) : cdiv(cmake(1, 0), pv);
+                const T inv = singular ? LU_MK(0, 0) : cdiv(LU_MK(1, 0), pv);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (p != jj) {
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* 
                         }
                     }
                     if (rows[r] > jj && rows[r] < N) {
-                        const cplx l = cmul(a[r][j], inv);
+                        const T l = cmul(a[r][j], inv);
                         a[r][j] = l;
 #pragma unroll
                         for (int w = j + 1; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, rowB[w]));
@@ -383,9 +406,10 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(cplx* const* 
 }
 
 // apply the row interchanges piv[p0 .. p0+np) to the columns [a0,a1) and [b0,b1)
-__global__ __launch_bounds__(FH_BLOCK) void k_lu_laswp(cplx* const* LUs, int* const* pivs, int N, int p0, int np,
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_laswp(T* const* LUs, int* const* pivs, int N, int p0, int np,
                                                         int a0, int a1, int b0, int b1) {
-    cplx* A = LUs[blockIdx.y];
+    T* A = LUs[blockIdx.y];
     const int* piv = pivs[blockIdx.y];
     const int id = blockIdx.x * FH_BLOCK + threadIdx.x;
     const int na = a1 - a0;
@@ -394,7 +418,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_laswp(cplx* const* LUs, int* co
     for (int j = 0; j < np; ++j) {
         int p = piv[p0 + j];
         if (p != p0 + j) {
-            cplx u = A[(size_t)c * N + p0 + j];
+            T u = A[(size_t)c * N + p0 + j];
             A[(size_t)c * N + p0 + j] = A[(size_t)c * N + p];
             A[(size_t)c * N + p] = u;
         }
@@ -402,10 +426,10 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_laswp(cplx* const* LUs, int* co
 }
 
 // U block row: A[k0:k0+NB, c] = L11^{-1} A[k0:k0+NB, c] for columns c in [c0,c1); one thread per column
-template <int NB>
-__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, int k0, int c0, int c1) {
-    cplx* A = LUs[blockIdx.y];
-    __shared__ cplx L[NB][NB + 1];
+template <int NB, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(T* const* LUs, int N, int k0, int c0, int c1) {
+    T* A = LUs[blockIdx.y];
+    __shared__ T L[NB][NB + 1];
     for (int e = threadIdx.x; e < NB * NB; e += FH_BLOCK) {
         int i = e % NB, j = e / NB;
         L[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
@@ -413,7 +437,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, i
     __syncthreads();
     const int c = c0 + blockIdx.x * FH_BLOCK + threadIdx.x;
     if (c >= c1) return;
-    cplx x[NB];
+    T x[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) x[i] = A[(size_t)c * N + k0 + i];
 #pragma unroll
@@ -434,14 +458,12 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(cplx* const* LUs, int N, i
 // Complex product with two accumulators per tile: Re += ur*lr + (-ui)*li, Im += ur*li + ui*lr.
 // The two-level factorisation calls it with kd = 32 inside an outer block column and kd = 128
 // for the trailing matrix, which is then read and written once per 128 eliminated columns.
-typedef double lu_v4d __attribute__((ext_vector_type(4)));
-
-template <int KC>
-__global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
+template <int KC, typename T>
+__global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
                                                        int c1, int TR, int TC) {
-    cplx* A = LUs[blockIdx.y];
-    __shared__ cplx Ls[KC][64];
-    __shared__ cplx Us[KC][64];
+    T* A = LUs[blockIdx.y];
+    __shared__ T Ls[KC][64];
+    __shared__ T Us[KC][64];
     const int t = threadIdx.x;
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so XCD x takes the
     // 8x8 super-tiles x, x+8, ... and walks one super-tile with 64 consecutive local slots:
@@ -457,23 +479,23 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N
     const int wi = (wave & 1) * 32, wc = (wave >> 1) * 32;     // wave's 32x32 sub-tile
     const int lr = lane & 15, lk = lane >> 4;
     constexpr int PF = KC * 64 / FH_BLOCK;                     // panel entries per thread and chunk
-    cplx pl[PF], pu[PF];
+    T pl[PF], pu[PF];
     auto fetch = [&](int kc) {
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const int e = t + q * FH_BLOCK;
             const int ii = e % 64, kl = e / 64;
-            pl[q] = (i0 + ii < r1) ? A[(size_t)(k0 + kc + kl) * N + i0 + ii] : cmake(0, 0);
+            pl[q] = (i0 + ii < r1) ? A[(size_t)(k0 + kc + kl) * N + i0 + ii] : LU_MK(0, 0);
             const int ku = e % KC, cc = e / KC;
-            pu[q] = (cc0 + cc < c1) ? A[(size_t)(cc0 + cc) * N + k0 + kc + ku] : cmake(0, 0);
+            pu[q] = (cc0 + cc < c1) ? A[(size_t)(cc0 + cc) * N + k0 + kc + ku] : LU_MK(0, 0);
         }
     };
     fetch(0);
-    lu_v4d re[2][2], im[2][2];
+    typename lu_el<T>::v4 re[2][2], im[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) { re[a][b] = (lu_v4d){0, 0, 0, 0}; im[a][b] = re[a][b]; }
+        for (int b = 0; b < 2; ++b) { re[a][b] = (typename lu_el<T>::v4){0, 0, 0, 0}; im[a][b] = re[a][b]; }
     auto stage = [&]() {
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N
     auto mma = [&]() {
 #pragma unroll 2
         for (int kk = 0; kk < KC; kk += 4) {
-            cplx u[2], l[2];
+            T u[2], l[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) u[a] = Us[kk + lk][wc + 16 * a + lr];
 #pragma unroll
@@ -495,15 +517,15 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].x, re[a][b], 0, 0, 0);
-                    im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].x, l[b].y, im[a][b], 0, 0, 0);
+                    re[a][b] = lu_el<T>::mfma(u[a].x, l[b].x, re[a][b]);
+                    im[a][b] = lu_el<T>::mfma(u[a].x, l[b].y, im[a][b]);
                 }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    re[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(-u[a].y, l[b].y, re[a][b], 0, 0, 0);
-                    im[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[a].y, l[b].x, im[a][b], 0, 0, 0);
+                    re[a][b] = lu_el<T>::mfma(-u[a].y, l[b].y, re[a][b]);
+                    im[a][b] = lu_el<T>::mfma(u[a].y, l[b].x, im[a][b]);
                 }
         }
     };
@@ -519,16 +541,16 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N
     if (kc) __syncthreads();
     stage();
     __syncthreads();
-    cplx cv[2][2][4];
+    T cv[2][2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = cc0 + wc + 16 * a + lk + 4 * r;
+                const int c = cc0 + wc + 16 * a + lu_el<T>::mrow(lk, r);
                 const int i = i0 + wi + 16 * b + lr;
-                cv[a][b][r] = (i < r1 && c < c1) ? A[(size_t)c * N + i] : cmake(0, 0);
+                cv[a][b][r] = (i < r1 && c < c1) ? A[(size_t)c * N + i] : LU_MK(0, 0);
             }
     mma();
 #pragma unroll
@@ -537,10 +559,10 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(cplx* const* LUs, int N
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = cc0 + wc + 16 * a + lk + 4 * r;
+                const int c = cc0 + wc + 16 * a + lu_el<T>::mrow(lk, r);
                 const int i = i0 + wi + 16 * b + lr;
                 if (i < r1 && c < c1) {
-                    cplx v = cv[a][b][r];
+                    T v = cv[a][b][r];
                     v.x -= re[a][b][r];
                     v.y -= im[a][b][r];
                     A[(size_t)c * N + i] = v;
@@ -583,38 +605,38 @@ __global__ void k_build_perm_global(int* const* pivs, int N) {
 // inv = LU + N*N + (2*block + upper)*NB*NB, column-major, identity-padded in a short last
 // block.  The block triangular solves then become products (k_solve_step), which removes the
 // nb-step sequential substitution from the critical path of every block step.
-template <int NB>
-__global__ __launch_bounds__(64) void k_lu_invert_diag(cplx* const* LUs, int N) {
-    cplx* A = LUs[blockIdx.y];
+template <int NB, typename T>
+__global__ __launch_bounds__(64) void k_lu_invert_diag(T* const* LUs, int N) {
+    T* A = LUs[blockIdx.y];
     const int k0 = blockIdx.x * NB;
     const int nb = min(NB, N - k0);
-    cplx* inv = A + (size_t)N * N + (size_t)blockIdx.x * 2 * NB * NB;
-    __shared__ cplx T[NB][NB + 1];
-    __shared__ cplx Li[NB][NB + 1];
-    __shared__ cplx Ui[NB][NB + 1];
+    T* inv = A + (size_t)N * N + (size_t)blockIdx.x * 2 * NB * NB;
+    __shared__ T Tb[NB][NB + 1];
+    __shared__ T Li[NB][NB + 1];
+    __shared__ T Ui[NB][NB + 1];
     const int t = threadIdx.x;
     for (int e = t; e < NB * NB; e += 64) {
         int i = e % NB, j = e / NB;
-        T[i][j] = (i < nb && j < nb) ? A[(size_t)(k0 + j) * N + k0 + i] : cmake(i == j ? 1.0 : 0.0, 0.0);
-        Li[i][j] = cmake(0, 0);
-        Ui[i][j] = cmake(0, 0);
+        Tb[i][j] = (i < nb && j < nb) ? A[(size_t)(k0 + j) * N + k0 + i] : LU_MK(i == j ? 1.0 : 0.0, 0.0);
+        Li[i][j] = LU_MK(0, 0);
+        Ui[i][j] = LU_MK(0, 0);
     }
     __syncthreads();
     if (t < NB) {                       // column t of L^-1
         const int c = t;
-        Li[c][c] = cmake(1, 0);
+        Li[c][c] = LU_MK(1, 0);
         for (int i = c + 1; i < NB; ++i) {
-            cplx s = cmake(0, 0);
-            for (int j = c; j < i; ++j) cfma(s, T[i][j], Li[j][c]);
-            Li[i][c] = cmake(-s.x, -s.y);
+            T s = LU_MK(0, 0);
+            for (int j = c; j < i; ++j) cfma(s, Tb[i][j], Li[j][c]);
+            Li[i][c] = LU_MK(-s.x, -s.y);
         }
     } else if (t < 2 * NB) {            // column c of U^-1
         const int c = t - NB;
-        Ui[c][c] = cdiv(cmake(1, 0), T[c][c]);
+        Ui[c][c] = cdiv(LU_MK(1, 0), Tb[c][c]);
         for (int i = c - 1; i >= 0; --i) {
-            cplx s = cmake(0, 0);
-            for (int j = i + 1; j <= c; ++j) cfma(s, T[i][j], Ui[j][c]);
-            Ui[i][c] = cdiv(cmake(-s.x, -s.y), T[i][i]);
+            T s = LU_MK(0, 0);
+            for (int j = i + 1; j <= c; ++j) cfma(s, Tb[i][j], Ui[j][c]);
+            Ui[i][c] = cdiv(LU_MK(-s.x, -s.y), Tb[i][i]);
         }
     }
     __syncthreads();
@@ -625,16 +647,27 @@ __global__ __launch_bounds__(64) void k_lu_invert_diag(cplx* const* LUs, int N) 
     }
 }
 
-// Y[node][i,:] = RHS[perm[i],:]
-__global__ __launch_bounds__(FH_BLOCK) void k_gather_rows(const cplx* __restrict__ RHS, int* const* perms,
-                                                           cplx* __restrict__ Y, size_t stride, int N, int ld) {
+// Y[node][i,:] = RHS[node][perm[i],:]   (rhs_stride = 0: one right-hand side panel shared by all nodes);
+// the fp64 right-hand side is narrowed to the factor precision here
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_gather_rows(const cplx* __restrict__ RHS, size_t rhs_stride, int* const* perms,
+                                                           T* __restrict__ Y, size_t stride, int N, int ld) {
     const int* perm = perms[blockIdx.y];
-    cplx* Yn = Y + (size_t)blockIdx.y * stride;
+    const cplx* Rn = RHS + (size_t)blockIdx.y * rhs_stride;
+    T* Yn = Y + (size_t)blockIdx.y * stride;
     const size_t total = (size_t)N * ld;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         size_t i = e / ld, c = e % ld;
-        Yn[e] = RHS[(size_t)perm[i] * ld + c];
+        Yn[e] = cvt<T>(Rn[(size_t)perm[i] * ld + c]);
     }
+}
+
+// complex64 solution panels back to the caller's fp64 panels
+__global__ __launch_bounds__(FH_BLOCK) void k_widen_panels(const cplxf* __restrict__ src, cplx* __restrict__ dst, size_t stride,
+                                                            size_t total) {
+    const cplxf* s = src + (size_t)blockIdx.y * stride;
+    cplx* d = dst + (size_t)blockIdx.y * stride;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) d[e] = to_d(s[e]);
 }
 
 // One block step of the triangular solves on row-major N x LD panels, one launch:
@@ -647,15 +680,15 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gather_rows(const cplx* __restrict
 // operands straight from global memory (A operand = 16 consecutive rows of one factor column,
 // 256 B per 16 lanes); complex product with two accumulators: Re += ar*br + (-ai)*bi,
 // Im += ar*bi + ai*br.  Wave w owns the 16-row band w of the 64-row tile and all LD columns.
-template <int NB, int LD, bool UPPER>
-__global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx* IN, cplx* OUT, size_t stride, int N,
+template <int NB, int LD, bool UPPER, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_step(T* const* LUs, T* IN, T* OUT, size_t stride, int N,
                                                           int k0, int r0, int r1, int rb, int cta) {
     static_assert(NB == 32, "tile mapping assumes NB == 32");
-    const cplx* A = LUs[blockIdx.y];
-    const cplx* inv = A + (size_t)N * N + ((size_t)(k0 / NB) * 2 + (UPPER ? 1 : 0)) * NB * NB;
-    cplx* in = IN + (size_t)blockIdx.y * stride;
-    cplx* out = OUT + (size_t)blockIdx.y * stride;
-    __shared__ cplx Zs[NB][LD + 1];
+    const T* A = LUs[blockIdx.y];
+    const T* inv = A + (size_t)N * N + ((size_t)(k0 / NB) * 2 + (UPPER ? 1 : 0)) * NB * NB;
+    T* in = IN + (size_t)blockIdx.y * stride;
+    T* out = OUT + (size_t)blockIdx.y * stride;
+    __shared__ T Zs[NB][LD + 1];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 15, lk = lane >> 4;
     constexpr int CT = LD / 16;
@@ -663,21 +696,21 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx*
     // cta = column tiles that hold active right-hand sides (the rest of the panel is padding)
     for (int q = wave; q < 2 * cta; q += 4) {
         const int ti = q / cta, ta = q % cta;
-        lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+        typename lu_el<T>::v4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
 #pragma unroll
         for (int kk = 0; kk < NB; kk += 4) {
-            const cplx a = inv[(size_t)(kk + lk) * NB + 16 * ti + lr];
+            const T a = inv[(size_t)(kk + lk) * NB + 16 * ti + lr];
             const int row = k0 + kk + lk;
-            const cplx b = row < N ? in[(size_t)row * LD + 16 * ta + lr] : cmake(0, 0);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, b.y, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.y, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.x, im, 0, 0, 0);
+            const T b = row < N ? in[(size_t)row * LD + 16 * ta + lr] : LU_MK(0, 0);
+            re = lu_el<T>::mfma(a.x, b.x, re);
+            re = lu_el<T>::mfma(-a.y, b.y, re);
+            im = lu_el<T>::mfma(a.x, b.y, im);
+            im = lu_el<T>::mfma(a.y, b.x, im);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + lk + 4 * r, c = 16 * ta + lr;
-            const cplx z = cmake(re[r], im[r]);
+            const int i = 16 * ti + lu_el<T>::mrow(lk, r), c = 16 * ta + lr;
+            const T z = LU_MK(re[r], im[r]);
             Zs[i][c] = z;
             if (blockIdx.x == 0 && k0 + i < N) out[(size_t)(k0 + i) * LD + c] = z;
         }
@@ -687,34 +720,34 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx*
     for (int band = wave; band < 4 * rb; band += 4) {
         const int ib = r0 + (blockIdx.x * 4 * rb + band) * 16;
         if (ib >= r1) break;
-        cplx am[NB / 4];
+        T am[NB / 4];
 #pragma unroll
         for (int s = 0; s < NB / 4; ++s) {
             const int col = k0 + 4 * s + lk;
-            am[s] = (ib + lr < r1 && col < N) ? A[(size_t)col * N + ib + lr] : cmake(0, 0);
+            am[s] = (ib + lr < r1 && col < N) ? A[(size_t)col * N + ib + lr] : LU_MK(0, 0);
         }
 #pragma unroll
         for (int ta = 0; ta < CT; ++ta) {
             if (ta >= cta) break;
-            cplx y[4];
+            T y[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ib + lk + 4 * r;
-                y[r] = i < r1 ? in[(size_t)i * LD + 16 * ta + lr] : cmake(0, 0);
+                const int i = ib + lu_el<T>::mrow(lk, r);
+                y[r] = i < r1 ? in[(size_t)i * LD + 16 * ta + lr] : LU_MK(0, 0);
             }
-            lu_v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+            typename lu_el<T>::v4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < NB / 4; ++s) {
-                const cplx b = Zs[4 * s + lk][16 * ta + lr];
-                re = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.x, re, 0, 0, 0);
-                re = __builtin_amdgcn_mfma_f64_16x16x4f64(-am[s].y, b.y, re, 0, 0, 0);
-                im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].x, b.y, im, 0, 0, 0);
-                im = __builtin_amdgcn_mfma_f64_16x16x4f64(am[s].y, b.x, im, 0, 0, 0);
+                const T b = Zs[4 * s + lk][16 * ta + lr];
+                re = lu_el<T>::mfma(am[s].x, b.x, re);
+                re = lu_el<T>::mfma(-am[s].y, b.y, re);
+                im = lu_el<T>::mfma(am[s].x, b.y, im);
+                im = lu_el<T>::mfma(am[s].y, b.x, im);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ib + lk + 4 * r;
-                if (i < r1) in[(size_t)i * LD + 16 * ta + lr] = cmake(y[r].x - re[r], y[r].y - im[r]);
+                const int i = ib + lu_el<T>::mrow(lk, r);
+                if (i < r1) in[(size_t)i * LD + 16 * ta + lr] = LU_MK(y[r].x - re[r], y[r].y - im[r]);
             }
         }
     }
@@ -723,6 +756,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(cplx* const* LUs, cplx*
 // ---------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------
+template <typename T>
 static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const std::vector<cplx>& zlist,
                            std::vector<int>& info_out) {
     // which: local node slots to (re)factor; zlist: their shifts
@@ -731,18 +765,18 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     const int N = (int)h->dense.N;
     void* p;
     int rc;
-    std::vector<cplx*> lus(nf);
+    std::vector<T*> lus(nf);
     std::vector<int*> pvs(nf);
-    for (int q = 0; q < nf; ++q) { lus[q] = (cplx*)h->lu_factors[which[q]]; pvs[q] = h->lu_pivots[which[q]]; }
-    if ((rc = fh_get_buf(h, "lu_ptrs", nf * sizeof(cplx*), &p))) return rc;
-    cplx** dlus = (cplx**)p;
+    for (int q = 0; q < nf; ++q) { lus[q] = (T*)h->lu_factors[which[q]]; pvs[q] = h->lu_pivots[which[q]]; }
+    if ((rc = fh_get_buf(h, "lu_ptrs", nf * sizeof(T*), &p))) return rc;
+    T** dlus = (T**)p;
     if ((rc = fh_get_buf(h, "lu_pptrs", nf * sizeof(int*), &p))) return rc;
     int** dpvs = (int**)p;
     if ((rc = fh_get_buf(h, "lu_z", nf * sizeof(cplx), &p))) return rc;
     cplx* dz = (cplx*)p;
     if ((rc = fh_get_buf(h, "lu_info", nf * sizeof(int), &p))) return rc;
     int* dinfo = (int*)p;
-    FH_CHECK(hipMemcpyAsync(dlus, lus.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(dlus, lus.data(), nf * sizeof(T*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemsetAsync(dinfo, 0, nf * sizeof(int), h->stream));
@@ -754,11 +788,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         fh_prof_begin(h, "lu_form");
         const bool bid = h->dense.b_identity != 0;
         if (h->dense.is_complex) {
-            if (bid) hipLaunchKernelGGL((k_form_shifted<cplx, true>), grid, block, 0, h->stream, (const cplx*)h->dense.A, (const cplx*)nullptr, dlus, dz, N);
-            else hipLaunchKernelGGL((k_form_shifted<cplx, false>), grid, block, 0, h->stream, (const cplx*)h->dense.A, (const cplx*)h->dense.B, dlus, dz, N);
+            if (bid) hipLaunchKernelGGL((k_form_shifted<cplx, true, T>), grid, block, 0, h->stream, (const cplx*)h->dense.A, (const cplx*)nullptr, dlus, dz, N);
+            else hipLaunchKernelGGL((k_form_shifted<cplx, false, T>), grid, block, 0, h->stream, (const cplx*)h->dense.A, (const cplx*)h->dense.B, dlus, dz, N);
         } else {
-            if (bid) hipLaunchKernelGGL((k_form_shifted<double, true>), grid, block, 0, h->stream, (const double*)h->dense.A, (const double*)nullptr, dlus, dz, N);
-            else hipLaunchKernelGGL((k_form_shifted<double, false>), grid, block, 0, h->stream, (const double*)h->dense.A, (const double*)h->dense.B, dlus, dz, N);
+            if (bid) hipLaunchKernelGGL((k_form_shifted<double, true, T>), grid, block, 0, h->stream, (const double*)h->dense.A, (const double*)nullptr, dlus, dz, N);
+            else hipLaunchKernelGGL((k_form_shifted<double, false, T>), grid, block, 0, h->stream, (const double*)h->dense.A, (const double*)h->dense.B, dlus, dz, N);
         }
         fh_prof_end(h);
     }
@@ -769,12 +803,12 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         const int ncols = (a1 - a0) + (b1 - b0);
         if (ncols <= 0) return;
         fh_prof_begin(h, "lu_laswp");
-        hipLaunchKernelGGL(k_lu_laswp, dim3((ncols + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, dpvs, N, p0, np, a0, a1, b0, b1);
+        hipLaunchKernelGGL((k_lu_laswp<T>), dim3((ncols + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, dpvs, N, p0, np, a0, a1, b0, b1);
         fh_prof_end(h);
     };
     auto trsm = [&](int k0, int c0, int c1) {
         fh_prof_begin(h, "lu_trsm");
-        hipLaunchKernelGGL((k_lu_trsm<LU_NB>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
+        hipLaunchKernelGGL((k_lu_trsm<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
         fh_prof_end(h);
     };
     auto gemm = [&](int k0, int kd, int r0, int r1, int c0, int c1, const char* cls) {
@@ -783,7 +817,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
         const int sw = std::min(8, TC);
         const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
-        hipLaunchKernelGGL((k_lu_gemm<LU_NB>), dim3(((nsuper + 7) / 8) * 8 * 8 * sw, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+        hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), dim3(((nsuper + 7) / 8) * 8 * 8 * sw, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
         fh_prof_end(h);
     };
     const int KB = h->lu_outer_block;
@@ -795,11 +829,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
             {
                 const int nrows = N - k0;
                 const dim3 g(nf), b(LU_PANEL_THREADS);
-                if (h->lu_panel_legacy || nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL(k_lu_panel, g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                if (h->lu_panel_legacy || nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
             }
             fh_prof_end(h);
             // interchanges inside the block column (left: finished L columns, right: still to eliminate)
@@ -820,7 +854,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         }
     }
     fh_prof_begin(h, "lu_invert");
-    hipLaunchKernelGGL((k_lu_invert_diag<LU_NB>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, N);
+    hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, N);
     if (N <= 16000) hipLaunchKernelGGL(k_build_perm, dim3(nf), dim3(FH_BLOCK), (size_t)N * sizeof(int), h->stream, dpvs, N);
     else hipLaunchKernelGGL(k_build_perm_global, dim3(nf), dim3(64), 0, h->stream, dpvs, N);
     fh_prof_end(h);
@@ -837,57 +871,77 @@ static int lu_solve_rb(int rows, int nf) {
     return std::max(1, std::min(8, rb));
 }
 
-template <int LD>
-static void lu_solve_launch(feasthip_ctx* h, cplx** dlus, cplx* Y, cplx* Z, size_t stride, int N, int nf, int m) {
+template <int LD, typename T>
+static void lu_solve_launch(feasthip_ctx* h, T** dlus, T* Y, T* Z, size_t stride, int N, int nf, int m) {
     const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
     const int nblocks = (N + LU_NB - 1) / LU_NB;
     for (int b = 0; b < nblocks; ++b) {        // forward: L z = P b   (Y -> Z)
         const int k0 = b * LU_NB, r0 = std::min(N, k0 + LU_NB);
         const int rb = lu_solve_rb(N - r0, nf);
         const int gx = std::max(1, (N - r0 + 64 * rb - 1) / (64 * rb));
-        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, false>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, k0, r0, N, rb, cta);
+        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, false, T>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, k0, r0, N, rb, cta);
     }
     for (int b = nblocks - 1; b >= 0; --b) {   // backward: U x = z   (Z -> Y)
         const int k0 = b * LU_NB;
         const int rb = lu_solve_rb(k0, nf);
         const int gx = std::max(1, (k0 + 64 * rb - 1) / (64 * rb));
-        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, true>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, k0, 0, k0, rb, cta);
+        hipLaunchKernelGGL((k_solve_step<LU_NB, LD, true, T>), dim3(gx, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, k0, 0, k0, rb, cta);
     }
 }
 
-static int lu_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
+// Solve with the cached factors of `slots`.  RHS: fp64 panel(s), rhs_stride = 0 when one panel is shared by
+// all nodes; Y: fp64 output panels.  T = cplxf: the right-hand side is narrowed while it is permuted, the
+// substitutions run in complex64 and the result is widened into Y (one step of the refinement loop).
+template <typename T>
+static int lu_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<int>& slots, const cplx* RHS, size_t rhs_stride,
+                          cplx* Y, size_t stride) {
     const int nf = (int)slots.size();
     const int N = (int)h->dense.N;
     void* p;
     int rc;
-    std::vector<cplx*> lus(nf);
+    std::vector<T*> lus(nf);
     std::vector<int*> perms(nf);
-    for (int q = 0; q < nf; ++q) { lus[q] = (cplx*)h->lu_factors[slots[q]]; perms[q] = h->lu_pivots[slots[q]] + N; }
-    if ((rc = fh_get_buf(h, "lu_ptrs", nf * sizeof(cplx*), &p))) return rc;
-    cplx** dlus = (cplx**)p;
+    for (int q = 0; q < nf; ++q) { lus[q] = (T*)h->lu_factors[slots[q]]; perms[q] = h->lu_pivots[slots[q]] + N; }
+    if ((rc = fh_get_buf(h, "lu_ptrs", nf * sizeof(T*), &p))) return rc;
+    T** dlus = (T**)p;
     if ((rc = fh_get_buf(h, "lu_permptrs", nf * sizeof(int*), &p))) return rc;
     int** dperms = (int**)p;
-    if ((rc = fh_get_buf(h, "lu_zpanel", (size_t)nf * stride * sizeof(cplx), &p))) return rc;
-    cplx* Z = (cplx*)p;
-    FH_CHECK(hipMemcpyAsync(dlus, lus.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
+    if ((rc = fh_get_buf(h, "lu_zpanel", (size_t)nf * stride * sizeof(T), &p))) return rc;
+    T* Z = (T*)p;
+    T* W = (T*)Y;                                   // working panel: Y itself in fp64, a complex64 buffer otherwise
+    if (sizeof(T) != sizeof(cplx)) {
+        if ((rc = fh_get_buf(h, "lu_wpanel", (size_t)nf * stride * sizeof(T), &p))) return rc;
+        W = (T*)p;
+    }
+    FH_CHECK(hipMemcpyAsync(dlus, lus.data(), nf * sizeof(T*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(dperms, perms.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_begin(h, "lu_solve");
-    hipLaunchKernelGGL(k_gather_rows, dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, dperms, Y, stride, N, ld);
-    if (ld == 16) lu_solve_launch<16>(h, dlus, Y, Z, stride, N, nf, m);
-    else if (ld == 32) lu_solve_launch<32>(h, dlus, Y, Z, stride, N, nf, m);
-    else lu_solve_launch<64>(h, dlus, Y, Z, stride, N, nf, m);
+    hipLaunchKernelGGL((k_gather_rows<T>), dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, rhs_stride, dperms, W, stride, N, ld);
+    if (ld == 16) lu_solve_launch<16, T>(h, dlus, W, Z, stride, N, nf, m);
+    else if (ld == 32) lu_solve_launch<32, T>(h, dlus, W, Z, stride, N, nf, m);
+    else lu_solve_launch<64, T>(h, dlus, W, Z, stride, N, nf, m);
+    if constexpr (sizeof(T) != sizeof(cplx))
+        hipLaunchKernelGGL(k_widen_panels, dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, (const cplxf*)W, Y, stride, (size_t)N * ld);
     fh_prof_end(h);
     return 0;
 }
 
 static int lu_ensure_slots(feasthip_ctx* h, int nslots) {
     const size_t N = (size_t)h->dense.N;
+    const int prec = h->factor_precision == 32 ? 32 : 64;
+    if (h->lu_prec != prec) {                       // factor precision changed: drop the cached factors
+        for (void* p : h->lu_factors) if (p) hipFree(p);
+        for (int* p : h->lu_pivots) if (p) hipFree(p);
+        h->lu_factors.clear(); h->lu_pivots.clear(); h->lu_valid.clear(); h->lu_z.clear();
+        h->lu_prec = prec;
+    }
+    const size_t esz = prec == 32 ? sizeof(cplxf) : sizeof(cplx);
     while ((int)h->lu_factors.size() < nslots) {
         void* f = nullptr; int* pv = nullptr;
         // factor, then the inverted diagonal blocks (k_lu_invert_diag); pivots, then the row permutation
         const size_t nblk = (N + LU_NB - 1) / LU_NB;
-        FH_CHECK(hipMalloc(&f, (N * N + nblk * 2 * LU_NB * LU_NB) * sizeof(cplx)));
+        FH_CHECK(hipMalloc(&f, (N * N + nblk * 2 * LU_NB * LU_NB) * esz));
         hipError_t e = hipMalloc((void**)&pv, 2 * N * sizeof(int));
         if (e != hipSuccess) { hipFree(f); h->last_error = "hipMalloc(pivots)"; return FEASTHIP_ERROR_MEMORY; }
         h->lu_factors.push_back(f); h->lu_pivots.push_back(pv); h->lu_valid.push_back(0); h->lu_z.push_back(cmake(0, 0));
@@ -896,8 +950,9 @@ static int lu_ensure_slots(feasthip_ctx* h, int nslots) {
 }
 
 int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
-                            cplx* Y, size_t stride, std::vector<int>& status, int64_t* nfact) {
+                            size_t rhs_stride, cplx* Y, size_t stride, std::vector<int>& status, int64_t* nfact) {
     int rc = lu_ensure_slots(h, nodes);
+    const bool f32 = h->lu_prec == 32;
     if (rc) return rc;
     std::vector<int> need;
     std::vector<cplx> zl;
@@ -906,7 +961,7 @@ int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std
         if (!ok) { need.push_back(e); zl.push_back(z[e]); h->lu_valid[e] = 0; }
     }
     std::vector<int> info;
-    if ((rc = lu_factor_batch(h, need, zl, info))) return rc;
+    if ((rc = f32 ? lu_factor_batch<cplxf>(h, need, zl, info) : lu_factor_batch<cplx>(h, need, zl, info))) return rc;
     for (size_t q = 0; q < need.size(); ++q) {
         h->lu_z[need[q]] = zl[q];
         h->lu_valid[need[q]] = info[q] == 0 ? 1 : -1;   // -1: singular
@@ -914,7 +969,8 @@ int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std
     if (nfact) *nfact = (int64_t)need.size();
     std::vector<int> slots(nodes);
     for (int e = 0; e < nodes; ++e) slots[e] = e;
-    if ((rc = lu_solve_batch(h, ld, m, slots, RHS, Y, stride))) return rc;
+    if ((rc = f32 ? lu_solve_batch<cplxf>(h, ld, m, slots, RHS, rhs_stride, Y, stride)
+                  : lu_solve_batch<cplx>(h, ld, m, slots, RHS, rhs_stride, Y, stride))) return rc;
     status.assign(nodes, 0);
     for (int e = 0; e < nodes; ++e) if (h->lu_valid[e] != 1) status[e] = FEASTHIP_ERROR_LAPACK;
     return 0;
@@ -932,16 +988,18 @@ int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx*
     }
     int rc = lu_ensure_slots(h, std::max(slot, h->node_count) + 1);
     if (rc) return rc;
+    const bool f32 = h->lu_prec == 32;
     std::vector<int> need(1, slot), info;
     std::vector<cplx> zl(1, z);
     bool cached = h->cache_factors && h->lu_valid[slot] == 1 && h->lu_z[slot].x == z.x && h->lu_z[slot].y == z.y;
     if (!cached) {
-        if ((rc = lu_factor_batch(h, need, zl, info))) return rc;
+        if ((rc = f32 ? lu_factor_batch<cplxf>(h, need, zl, info) : lu_factor_batch<cplx>(h, need, zl, info))) return rc;
         h->lu_z[slot] = z;
         h->lu_valid[slot] = info[0] == 0 ? 1 : -1;
         if (nfact) *nfact = 1;
     }
-    if ((rc = lu_solve_batch(h, ld, m, need, RHS, Y, (size_t)h->dense.N * ld))) return rc;
+    if ((rc = f32 ? lu_solve_batch<cplxf>(h, ld, m, need, RHS, 0, Y, (size_t)h->dense.N * ld)
+                  : lu_solve_batch<cplx>(h, ld, m, need, RHS, 0, Y, (size_t)h->dense.N * ld))) return rc;
     *status = h->lu_valid[slot] == 1 ? 0 : FEASTHIP_ERROR_LAPACK;
     return 0;
 }

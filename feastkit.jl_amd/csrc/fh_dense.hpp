@@ -23,7 +23,7 @@ void fh_launch_axpy_cols(cplx* R, const cplx* X, const cplx* lam, int N, int ld,
 
 // Factor (cached per local node when h->cache_factors) and solve all local nodes:
 //   Y[e] = (z_e B - A)^{-1} RHS     RHS: one shared panel; Y: node-strided panels
-int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS,
+int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, size_t rhs_stride,
                             cplx* Y, size_t stride, std::vector<int>& status, int64_t* nfact);
 // one-off (uncached) solve for a single shift
 int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status,

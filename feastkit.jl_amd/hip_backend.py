@@ -196,7 +196,12 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         engine.set_solver(solver, rtol=rt, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
                           factor_precision=inner_precision)
     elif inner_precision == 32:
-        raise ValueError("inner_precision=32 requires the warm-started inexact iterative mode")
+        if solver in ("direct", "lu"):
+            # dense LU: complex64 factors + fp64 iterative refinement inside every solve
+            engine.set_solver(solver, rtol=tol_value, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
+                              factor_precision=32, cache_factors=True)
+        else:
+            raise ValueError("inner_precision=32 needs the dense LU solver or the warm-started inexact iterative mode")
     t_setup = time.perf_counter() - t_setup
 
     if Q0 is not None and hasattr(Q0, "data_ptr"):
@@ -345,7 +350,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
 
 
 def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
-                      solver_restart=30, group=None, Q0=None, seed=20260515):
+                      solver_restart=30, group=None, Q0=None, seed=20260515, inner_precision=64):
     """Variant C (general, full contour, no factor 2, no orthonormalisation, residual
     without B): src/kernel/feast_kernel.jl:752-950 driven as in src/dense/feast_dense.jl:468-584."""
     N = A.shape[0]
@@ -367,15 +372,23 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
     engine.set_real_projection(False)
     first, count = distribute_contour_points(len(Zne), world)[rank]
     engine.set_node_range(first, count)
+    if inner_precision == 32 and solver not in ("direct", "lu"):
+        raise ValueError("inner_precision=32 (complex64 LU factors + fp64 refinement) needs the dense LU solver")
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
-                      restart=solver_restart, cache_factors=True)
+                      restart=solver_restart, cache_factors=True, factor_precision=32 if inner_precision == 32 else 64)
     Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
     dQ = engine.upload(Q_host)
     eps_tol = feast_tolerance(fpm)
     maxloop = int(fpm[4])
     loop = 0
     stats = {"krylov_iterations": 0, "factorizations": 0, "solve_seconds": 0.0}
+    epsout = math.inf
     while True:
+        if inner_precision == 32:
+            # inexact FEAST: the complex64 solves are refined only as far as the current outer residual needs
+            ref_tol = 1.0 if not math.isfinite(epsout) else min(1.0, max(1e-14, 1e-2 * epsout))
+            engine.set_solver(solver, rtol=ref_tol, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
+                              cache_factors=True, factor_precision=32)
         dq, status, st = engine.contour_apply(dQ, M0, None)
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
         stats["factorizations"] += st.get("factorizations", 0)

@@ -141,9 +141,12 @@ int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
 
 /* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
  * (src/dense/feast_dense.jl:81-84).  Iterative stop test is Krylov.jl's
- * ||r_k|| <= atol + rtol*||r_0|| per column.  factor_precision 64|32: 32 runs the BiCGStab/COCG
- * correction solve on complex64 panels around an fp64 residual (CSR input, inexact-solve mode);
- * the dense LU path always factors in complex128.  cache_factors: keep LU factors per
+ * ||r_k|| <= atol + rtol*||r_0|| per column.  factor_precision 64|32: 32 = mixed precision.  Dense LU:
+ * complex64 factors and substitutions (f32 MFMA) inside an fp64 iterative-refinement loop (residual by the
+ * fp64 operator kernel, stop at 1e-14 relative, <= 8 steps) -- fp64-accurate solves while
+ * cond(zB-A)*eps32 < 1 (the reference has no counterpart; BASELINE config 5 asks for it).
+ * BiCGStab/COCG: correction solve on complex64 panels around an fp64 residual (inexact-solve mode).
+ * cache_factors: keep LU factors per
  * node across calls (src/dense/feast_dense.jl:147,188).                                 */
 int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit,
                          int restart, int factor_precision, int cache_factors);

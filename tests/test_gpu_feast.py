@@ -251,6 +251,11 @@ def test_cfg5_reduced_general_dense(engine):
     assert np.allclose(sorted(r.lambda_, key=key), sorted(inside, key=key), atol=1e-9)
     assert np.allclose(sorted(r.lambda_, key=key), sorted(o.lam, key=key), atol=1e-9)
     assert r.epsout <= 1e-11
+    # BASELINE config 5 as written: ComplexF32 factors, fp64 refinement -- the same eigenvalues and loop count
+    rm = fk.feast_general(A, None, 0.0, 1.5, M0=M0, fpm=fpm_with(f8=24, f4=40), engine=engine, inner_precision=32)
+    assert rm.info == 0 and rm.M == len(inside) and abs(rm.loop - r.loop) <= 1
+    assert np.allclose(sorted(rm.lambda_, key=key), sorted(inside, key=key), atol=1e-9)
+    assert rm.epsout <= 1e-11
 
 
 def test_empty_and_edge_inputs(engine):

@@ -156,7 +156,9 @@ def test_bicgstab_shifted_solve(engine, N, m):
 
 @pytest.mark.parametrize("N,m", [(33, 5), (100, 10), (500, 32), (1111, 64)])
 @pytest.mark.parametrize("cplx,bid", [(False, True), (False, False), (True, False)])
-def test_dense_lu_shifted_solve(engine, N, m, cplx, bid):
+@pytest.mark.parametrize("prec", [64, 32])
+def test_dense_lu_shifted_solve(engine, N, m, cplx, bid, prec):
+    """prec 32: complex64 factors (f32 MFMA) + fp64 iterative refinement -- same accuracy bar as fp64 LU."""
     rng = np.random.default_rng(N)
     A = rng.standard_normal((N, N)); A = A + A.T
     if cplx:
@@ -165,10 +167,11 @@ def test_dense_lu_shifted_solve(engine, N, m, cplx, bid):
     if not bid:
         B = rng.standard_normal((N, N)); B = B @ B.T / N + np.eye(N)
     engine.set_problem(A, B)
-    engine.set_solver("direct")
+    engine.set_solver("direct", factor_precision=prec)
     z = 0.3 + 0.7j
     X = rand_block(N, m, 4)
     dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    engine.set_solver("direct")
     assert rc == 0
     Y = engine.download(dY)
     Sm = z * (np.eye(N) if B is None else B) - A

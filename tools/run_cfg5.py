@@ -1,5 +1,5 @@
 """cfg 5 at full size on one GPU: complex non-Hermitian N=8192, centre 0 radius 2, 24 nodes, M0=48.
-Usage: python tools/run_cfg5.py [N] [ne]"""
+Usage: python tools/run_cfg5.py [N] [ne] [64|32]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,6 +7,7 @@ import numpy as np
 import feastkit_jl_amd as fk
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 ne = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+prec = int(sys.argv[3]) if len(sys.argv) > 3 else 64       # 32: complex64 LU factors + fp64 refinement
 A, delta = fk.workloads.disc_spectrum_general(N)
 inside = delta[np.abs(delta) <= 2.0]
 print("N", N, "inside", len(inside), flush=True)
@@ -14,7 +15,7 @@ eng = fk.HipEngine(0)
 fpm = fk.feastinit(); fpm[8] = ne; fpm[4] = 20
 eng.profile_reset(); eng.profile_enable(True)
 t0 = time.perf_counter()
-r = fk.feast_hip_general(eng, A, None, 0.0, 2.0, 48, fpm)
+r = fk.feast_hip_general(eng, A, None, 0.0, 2.0, 48, fpm, inner_precision=prec)
 dt = time.perf_counter() - t0
 key = lambda x: (round(x.real, 7), round(x.imag, 7))
 err = np.abs(np.array(sorted(r.lambda_, key=key)) - np.array(sorted(inside, key=key))).max() if r.M == len(inside) else None
