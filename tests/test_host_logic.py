@@ -309,3 +309,23 @@ def test_zolotarev_hermitian_solve_matches_oracle():
     want = fo.feast_hermitian(A, None, lo, hi, 12, ne=8, fpm16=2, fpm4=40, real_projection=True)
     assert (got.info, got.M) == (want.info, want.M) == (0, 8)
     assert np.allclose(got.lambda_, ev[8:16], atol=1e-10) and np.allclose(got.lambda_, want.lam, atol=1e-10)
+
+
+# ---- banded drivers (src/banded/feast_banded.jl) through the CPU stand-in engine ----------------------
+def test_banded_drivers_host_logic():
+    from feastkit_jl_amd import ingest
+    import scipy.sparse as _sp
+    n = 60
+    rng = np.random.default_rng(13)
+    o1 = 0.4 * (rng.standard_normal(n - 1) + 1j * rng.standard_normal(n - 1))
+    H = _sp.diags([o1.conj(), np.linspace(1, 9, n), o1], [-1, 0, 1]).toarray()
+    Hb = ingest.csr_to_band_upper(_sp.csr_matrix(H), 1)
+    ev = np.linalg.eigvalsh(H)
+    lo, hi = 0.5 * (ev[9] + ev[10]), 0.5 * (ev[15] + ev[16])
+    fpm = fk.feastinit(); fpm[2] = 8; fpm[3] = 10; fpm[4] = 60
+    r = fk.feast_hbev(Hb, 1, lo, hi, 10, fpm, engine=OracleEngine())
+    assert r.info == 0 and r.M == 6 and np.allclose(r.lambda_, ev[10:16], atol=1e-8)
+    with pytest.raises(ValueError):
+        fk.feast_hbev(Hb, 1, lo, hi, 10, fk.feastinit(), engine=OracleEngine(), solver="cholesky")
+    with pytest.raises(ValueError):
+        fk.feast_sbev(np.zeros((1, 5)), 2, 0.0, 1.0, 2, engine=OracleEngine())

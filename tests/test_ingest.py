@@ -92,3 +92,29 @@ def test_file_to_device_solve(engine, tmp_path):
     r = fk.feast_hip_hermitian(engine, S, None, lo, hi, 12, fpm, solver="bicgstab", solver_tol=1e-13, solver_maxiter=4000,
                                real_projection=False)
     assert r.info == 0 and r.M == 8 and np.allclose(r.lambda_, ev[10:18], atol=1e-9)
+
+
+def test_band_storage_conversions():
+    """Band storage of the reference's banded drivers (src/banded/feast_banded.jl:205-271, 488-509)."""
+    rng = np.random.default_rng(0)
+    n, k = 11, 3
+    M = sum(np.diag(rng.standard_normal(n - abs(d)) + 1j * rng.standard_normal(n - abs(d)), d) for d in range(-k, k + 1))
+    S = np.triu(M.real) + np.triu(M.real, 1).T                              # real symmetric
+    H = np.triu(M) + np.triu(M, 1).conj().T
+    H[np.diag_indices(n)] = H.diagonal().real                               # Hermitian
+    Cs = np.triu(M) + np.triu(M, 1).T                                       # complex symmetric
+    for full, kind in ((S, "symmetric"), (H, "hermitian"), (Cs, "complex_symmetric")):
+        Ab = ingest.csr_to_band_upper(sp.csr_matrix(full), k)
+        assert Ab.shape == (k + 1, n)
+        for j in range(n):
+            for i in range(max(0, j - k), j + 1):
+                assert Ab[k + i - j, j] == full[i, j]                       # A(i,j) at row k+1+i-j (1-based)
+        back = ingest.band_upper_to_csr(Ab, k, kind).toarray()
+        assert np.array_equal(back, full)
+    G = np.zeros((2 * k + 1, n), dtype=complex)
+    for i in range(n):
+        for j in range(max(0, i - k), min(n, i + k + 1)):
+            G[k + i - j, j] = M[i, j]
+    assert np.array_equal(ingest.band_general_to_csr(G, k).toarray(), M)
+    with pytest.raises(ValueError):
+        ingest.band_upper_to_csr(np.zeros((2, 5)), 3)
