@@ -420,10 +420,17 @@ __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, i
     const int t = threadIdx.x;
     const int c = t % LD, g = t / LD;
     constexpr int G = FH_FIN_BLOCK / LD;
-    cplx s = cmake(0, 0);
-    const cplx* p = partial + (size_t)node * nblk * LD;
-    for (int b = g; b < nblk; b += G) s = cadd(s, p[(size_t)b * LD + c]);
-    red[t] = s;
+    cplx s0 = cmake(0, 0), s1 = cmake(0, 0);
+    const cplx* p = partial + (size_t)node * nblk * LD + c;
+    int b = g;
+    for (; b + 3 * G < nblk; b += 4 * G) {          // four independent loads in flight per thread
+        const cplx v0 = p[(size_t)b * LD], v1 = p[(size_t)(b + G) * LD], v2 = p[(size_t)(b + 2 * G) * LD],
+                   v3 = p[(size_t)(b + 3 * G) * LD];
+        s0 = cadd(s0, cadd(v0, v1));
+        s1 = cadd(s1, cadd(v2, v3));
+    }
+    for (; b < nblk; b += G) s0 = cadd(s0, p[(size_t)b * LD]);
+    red[t] = cadd(s0, s1);
     __syncthreads();
     cplx tot = cmake(0, 0);
     if (t < LD) {
@@ -432,6 +439,35 @@ __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, i
     }
     __syncthreads();
     return tot;  // valid for t < LD
+}
+
+// two partial arrays in one pass (one barrier pair instead of two, loads of both arrays overlap)
+template <int LD>
+__device__ __forceinline__ void fh_sum_partials2(const cplx* partial1, const cplx* partial2, int node, int nblk, cplx* red,
+                                                 cplx& tot1, cplx& tot2) {
+    const int t = threadIdx.x;
+    const int c = t % LD, g = t / LD;
+    constexpr int G = FH_FIN_BLOCK / LD;
+    cplx a0 = cmake(0, 0), a1 = cmake(0, 0), b0 = cmake(0, 0), b1 = cmake(0, 0);
+    const cplx* p = partial1 + (size_t)node * nblk * LD + c;
+    const cplx* q = partial2 + (size_t)node * nblk * LD + c;
+    int b = g;
+    for (; b + G < nblk; b += 2 * G) {
+        const cplx u0 = p[(size_t)b * LD], u1 = p[(size_t)(b + G) * LD];
+        const cplx w0 = q[(size_t)b * LD], w1 = q[(size_t)(b + G) * LD];
+        a0 = cadd(a0, u0); a1 = cadd(a1, u1);
+        b0 = cadd(b0, w0); b1 = cadd(b1, w1);
+    }
+    for (; b < nblk; b += G) { a0 = cadd(a0, p[(size_t)b * LD]); b0 = cadd(b0, q[(size_t)b * LD]); }
+    red[t] = cadd(a0, a1);
+    red[FH_FIN_BLOCK + t] = cadd(b0, b1);
+    __syncthreads();
+    tot1 = cmake(0, 0); tot2 = cmake(0, 0);
+    if (t < LD) {
+        tot1 = red[t]; tot2 = red[FH_FIN_BLOCK + t];
+        for (int k = 1; k < G; ++k) { tot1 = cadd(tot1, red[t + k * LD]); tot2 = cadd(tot2, red[FH_FIN_BLOCK + t + k * LD]); }
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ bool fh_finite(cplx a) { return isfinite(a.x) && isfinite(a.y); }
@@ -521,13 +557,13 @@ template <int LD>
 __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_rho(fh_fin_args a) {
     // mode 0: rho_new = <rhat, r>, beta = (rho_new/rho)(alpha/omega)   (BiCGStab)
     // mode 1: rho_new = r^T r,     beta = rho_new/rho                  (COCG)
-    __shared__ cplx red[FH_FIN_BLOCK];
+    __shared__ cplx red[2 * FH_FIN_BLOCK];
     __shared__ int cnt;
     const int node = blockIdx.x, t = threadIdx.x;
     if (a.s.node_active[node] == 0) return;
     if (t == 0) cnt = 0;
-    cplx rho_new = fh_sum_partials<LD>(a.partial1, node, a.nblk, red);
-    cplx rr = fh_sum_partials<LD>(a.partial2, node, a.nblk, red);
+    cplx rho_new, rr;
+    fh_sum_partials2<LD>(a.partial1, a.partial2, node, a.nblk, red, rho_new, rr);
     if (t < LD) {
         const int i = node * LD + t;
         if (a.s.active[i]) {
