@@ -167,6 +167,7 @@ extern "C" int feasthip_synchronize(feasthip_handle h) {
     FH_CHECK(hipSetDevice(h->device));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
 }
 
@@ -1132,6 +1133,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     }
     hipEventDestroy(ev0); hipEventDestroy(ev1);
     fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
 }
 
@@ -1467,6 +1469,7 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
     fh_launch_from_panel(res, ld, N, m, (cplx*)dQ, N, h->stream);
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
 }
 
@@ -1612,6 +1615,7 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
         memcpy(out_host, res.data(), res.size() * sizeof(cplx));
     }
     fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
 }
 
@@ -1812,6 +1816,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
     }
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
 }
 
@@ -1936,6 +1941,7 @@ extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, co
     fh_launch_from_panel(Yp, ld, N, m, (cplx*)dY, N, h->stream);
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
 }
 
