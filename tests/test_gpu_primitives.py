@@ -342,3 +342,30 @@ def test_rayleigh_ritz_reports_indefinite_b(engine):
     dQ = engine.upload(rand_block(N, 6, 1, cplx=False))
     assert engine.orthonormalize(dQ, 6, 1e-8) == 6
     assert engine.rayleigh_ritz(dQ, 6, 0.0, 10.0) is None
+
+
+def test_rayleigh_ritz_on_device_degenerate_spectrum(engine):
+    """Repeated reduced eigenvalues (the Jacobi sweeps must still converge and keep V^H A V = I): check
+    eigenvalues, residuals and B-orthonormality of the Ritz vectors instead of the vectors themselves."""
+    N, r = 400, 24
+    d = np.repeat(np.arange(1.0, 9.0), 50)                      # eigenvalues 1..8, each 50-fold
+    A = sp.csr_matrix(sp.diags([d], [0]))
+    B = sp.csr_matrix(sp.diags([1.0 + 0.01 * (np.arange(N) % 7)], [0]))
+    engine.set_problem(A, B)
+    rng = np.random.default_rng(3)
+    idx = np.concatenate([rng.choice(np.where(d == v)[0], 3, replace=False) for v in range(1, 9)])   # 3 per cluster
+    Q = np.zeros((N, r), dtype=np.complex128)
+    Q[idx, np.arange(r)] = 1.0
+    Q = Q @ np.linalg.qr(rng.standard_normal((r, r)) + 1j * rng.standard_normal((r, r)))[0]       # mix within the subspace
+    dQ = engine.upload(np.asfortranarray(Q))
+    out = engine.rayleigh_ritz(dQ, r, 2.5, 6.5, use_B=True)
+    assert out is not None
+    dX, lam, M, res = out
+    bdiag = B.diagonal()
+    want = np.sort(d[idx] / bdiag[idx])
+    assert M == int(np.sum((want >= 2.5) & (want <= 6.5)))
+    assert np.allclose(np.sort(lam), want, atol=1e-12)
+    assert res.max() <= 1e-12
+    X = engine.download(dX)[:, :M]
+    G = X.conj().T @ (B @ X)
+    assert np.abs(G - np.diag(np.diag(G))).max() <= 1e-12      # B-orthogonal (columns were normalised in 2-norm)
