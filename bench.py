@@ -194,7 +194,7 @@ def main():
     roofline = cands[0] if cands else None
     roofline_other = cands[1] if len(cands) > 1 else None
     classes = {}
-    for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz"):
+    for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz", "reduced_eig"):
         ms, n = eng.profile_get(cls)
         if n:
             classes[cls] = {"launches": int(n), "est_total_ms": round(ms, 2)}

@@ -1886,6 +1886,7 @@ extern "C" int feasthip_rayleigh_ritz_dev(feasthip_handle h, int64_t r64, const 
     FH_CHECK(hipMemcpyAsync(lam.data(), dlam, r * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipMemcpyAsync(V.data(), dV, V.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
+    if (getenv("FH_DEBUG_TIMING")) fprintf(stderr, "[rayleigh_ritz] r=%d jacobi sweeps=%d\n", r, flags[3]);
     if (flags[0] || flags[2]) { h->last_error = "rayleigh_ritz: reduced B matrix not positive definite"; return FEASTHIP_ERROR_LAPACK; }
     // stable inside-first permutation
     std::vector<int> perm;

@@ -6,6 +6,8 @@
 // sorted ascending like LAPACK, eigenvectors W = L^-H V so that W^H A W = I.  A real-symmetric
 // input keeps real rotations (the phase of a real off-diagonal entry is +-1), so the Ritz vectors of
 // the real-projection path stay real.
+#include <cstdlib>
+
 #include "fh_eig.hpp"
 
 #define EIG_THREADS 1024
@@ -14,10 +16,18 @@
 __device__ __forceinline__ cplx eig_conj(cplx a) { return cmake(a.x, -a.y); }
 
 // scratch layout (doubles/cplx in global memory, all tiny): Lg[64*64], Vg[64*64], rot[32*4], flags[4]
+// VLDS: the eigenvector accumulator and the rotation parameters live in (dynamic) LDS next to C -- 129 KB
+// per workgroup, which gfx950's 160 KB LDS allows; otherwise they stay in global memory (L2) and every one
+// of the ~1500 phases pays a memory round trip (2.6 ms instead of a fraction of that at r = 64).
+template <bool VLDS>
 __global__ __launch_bounds__(EIG_THREADS) void k_herm_eig(int r, int ld, const cplx* __restrict__ S,
-                                                          const cplx* __restrict__ A, cplx* Lg, cplx* Vg, double* rot,
+                                                          const cplx* __restrict__ A, cplx* Lg, cplx* Vglob, double* rotglob,
                                                           int* flags, double* lambda, cplx* Vout, int max_sweeps) {
-    __shared__ cplx C[EIG_MAX * EIG_MAX];                 // column-major, stride 64
+    extern __shared__ cplx eig_dyn[];
+    __shared__ cplx Cst[VLDS ? 1 : EIG_MAX * EIG_MAX];
+    cplx* C = VLDS ? eig_dyn : Cst;                       // column-major, stride 64
+    cplx* Vg = VLDS ? eig_dyn + EIG_MAX * EIG_MAX : Vglob;
+    double* rot = VLDS ? (double*)(eig_dyn + 2 * EIG_MAX * EIG_MAX) : rotglob;
     const int t = threadIdx.x;
     const int n = (r + 1) & ~1;                           // even size for the round-robin pairing
     // ---- load, Hermitian part
@@ -31,49 +41,52 @@ __global__ __launch_bounds__(EIG_THREADS) void k_herm_eig(int r, int ld, const c
             v = cmake(1e300, 0);                          // padding index: decoupled, sorts last
         }
         C[e] = v;
-        Vg[e] = cmake(i == j ? 1.0 : 0.0, 0.0);
+        if (!VLDS || !A) Vg[e] = cmake(i == j ? 1.0 : 0.0, 0.0);
     }
     if (t < 4) flags[t] = 0;
     __syncthreads();
+    // Cholesky factor: in LDS mode it borrows the eigenvector region until C = L^-1 S L^-H is formed, is
+    // then parked in global memory, and returns to LDS (in C's place) for the back-transformation
+    cplx* L = (VLDS && A) ? Vg : Lg;
     // ---- generalized problem: C = L^-1 C L^-H
     if (A) {
         for (int e = t; e < r * r; e += EIG_THREADS) {
             const int i = e % r, j = e / r;
             const cplx a = A[i + (size_t)j * ld], b = A[j + (size_t)i * ld];
-            Lg[i + j * EIG_MAX] = cmake(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
+            L[i + j * EIG_MAX] = cmake(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
         }
         __syncthreads();
         for (int k = 0; k < r; ++k) {
             if (t == 0) {
-                const double d = Lg[k + k * EIG_MAX].x;
+                const double d = L[k + k * EIG_MAX].x;
                 if (!(d > 0.0) || !isfinite(d)) flags[0] = k + 1;      // not positive definite
-                else Lg[k + k * EIG_MAX] = cmake(sqrt(d), 0);
+                else L[k + k * EIG_MAX] = cmake(sqrt(d), 0);
             }
             __syncthreads();
             if (flags[0]) return;
-            const double dk = Lg[k + k * EIG_MAX].x;
-            for (int i = k + 1 + t; i < r; i += EIG_THREADS) Lg[i + k * EIG_MAX] = cscale(Lg[i + k * EIG_MAX], 1.0 / dk);
+            const double dk = L[k + k * EIG_MAX].x;
+            for (int i = k + 1 + t; i < r; i += EIG_THREADS) L[i + k * EIG_MAX] = cscale(L[i + k * EIG_MAX], 1.0 / dk);
             __syncthreads();
             const int m = r - k - 1;
             for (int e = t; e < m * m; e += EIG_THREADS) {
                 const int i = k + 1 + e % m, j = k + 1 + e / m;
-                if (j <= i) Lg[i + j * EIG_MAX] = csub(Lg[i + j * EIG_MAX], cmul(Lg[i + k * EIG_MAX], eig_conj(Lg[j + k * EIG_MAX])));
+                if (j <= i) L[i + j * EIG_MAX] = csub(L[i + j * EIG_MAX], cmul(L[i + k * EIG_MAX], eig_conj(L[j + k * EIG_MAX])));
             }
             __syncthreads();
         }
         if (t < r) {                                       // column t of C <- L^-1 (column t)
             for (int i = 0; i < r; ++i) {
                 cplx x = C[i + t * EIG_MAX];
-                for (int k = 0; k < i; ++k) x = csub(x, cmul(Lg[i + k * EIG_MAX], C[k + t * EIG_MAX]));
-                C[i + t * EIG_MAX] = cscale(x, 1.0 / Lg[i + i * EIG_MAX].x);
+                for (int k = 0; k < i; ++k) x = csub(x, cmul(L[i + k * EIG_MAX], C[k + t * EIG_MAX]));
+                C[i + t * EIG_MAX] = cscale(x, 1.0 / L[i + i * EIG_MAX].x);
             }
         }
         __syncthreads();
         if (t < r) {                                       // row t of C <- (row t) L^-H
             for (int j = 0; j < r; ++j) {
                 cplx y = C[t + j * EIG_MAX];
-                for (int k = 0; k < j; ++k) y = csub(y, cmul(C[t + k * EIG_MAX], eig_conj(Lg[j + k * EIG_MAX])));
-                C[t + j * EIG_MAX] = cscale(y, 1.0 / Lg[j + j * EIG_MAX].x);
+                for (int k = 0; k < j; ++k) y = csub(y, cmul(C[t + k * EIG_MAX], eig_conj(L[j + k * EIG_MAX])));
+                C[t + j * EIG_MAX] = cscale(y, 1.0 / L[j + j * EIG_MAX].x);
             }
         }
         __syncthreads();
@@ -89,8 +102,26 @@ __global__ __launch_bounds__(EIG_THREADS) void k_herm_eig(int r, int ld, const c
             }
         }
         __syncthreads();
+        if (VLDS) {
+            for (int e = t; e < EIG_MAX * EIG_MAX; e += EIG_THREADS) {
+                const int i = e & 63, j = e >> 6;
+                if (i < r && j < r) Lg[e] = L[e];
+                Vg[e] = cmake(i == j ? 1.0 : 0.0, 0.0);
+            }
+            __syncthreads();
+        }
     }
     // ---- cyclic Jacobi, round-robin pairs
+    // entries cannot be driven below the rounding level eps*||C||: "still converging" is judged against
+    // the larger of the relative (small eigenvalues) and this absolute floor, or the sweeps never stop
+    __shared__ double s_scale;
+    if (t == 0) {
+        double mx = 0.0;
+        for (int i = 0; i < r; ++i) mx = fmax(mx, fabs(C[i + i * EIG_MAX].x));
+        s_scale = mx;
+    }
+    __syncthreads();
+    const double abs_floor = 4.5e-16 * s_scale;
     const int half = n / 2;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (t == 0) flags[1] = 0;
@@ -113,7 +144,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_herm_eig(int r, int ld, const c
                     const double s = tt * c;
                     sx = s * apq.x / beta;                  // s * e^{i phi}
                     sy = s * apq.y / beta;
-                    if (beta > 1e-15 * sqrt(fabs(app) * fabs(aqq)) + 1e-300) flags[1] = 1;   // still converging
+                    if (beta > fmax(1e-15 * sqrt(fabs(app) * fabs(aqq)), abs_floor)) flags[1] = 1;   // still converging
                 }
                 rot[4 * t + 0] = c; rot[4 * t + 1] = sx; rot[4 * t + 2] = sy;
                 rot[4 * t + 3] = (double)(p * EIG_MAX + q);
@@ -153,30 +184,48 @@ __global__ __launch_bounds__(EIG_THREADS) void k_herm_eig(int r, int ld, const c
             }
             __syncthreads();
         }
+        if (t == 0) flags[3] = sweep + 1;
         if (flags[1] == 0) break;                           // uniform: read after the barrier of the last round
         __syncthreads();
     }
     // ---- sort ascending, back-transform, write out
+    __shared__ double lam_s[EIG_MAX];
+    __shared__ int rank_s[EIG_MAX];
+    if (t < r) lam_s[t] = C[t + t * EIG_MAX].x;
+    __syncthreads();
     if (t < r) {
-        const double li = C[t + t * EIG_MAX].x;
+        const double li = lam_s[t];
         int rank = 0;
         for (int j = 0; j < r; ++j) {
-            const double lj = C[j + j * EIG_MAX].x;
+            const double lj = lam_s[j];
             if (lj < li || (lj == li && j < t)) ++rank;
         }
         if (!isfinite(li)) flags[2] = 1;
         lambda[rank] = li;
-        // column t of W = L^-H V  (back substitution), stored at position `rank`
-        cplx w[EIG_MAX];
+        rank_s[t] = rank;
+    }
+    const cplx* Lb = Lg;
+    if (VLDS && A) {                                        // C is no longer needed: bring L back into its place
+        __syncthreads();
+        for (int e = t; e < EIG_MAX * EIG_MAX; e += EIG_THREADS) {
+            const int i = e & 63, j = e >> 6;
+            if (i < r && j < r) C[e] = Lg[e];
+        }
+        Lb = C;
+    }
+    __syncthreads();
+    if (t < r) {
+        // column t of W = L^-H V  (back substitution, in place in V), stored at position rank_s[t]
+        const int rank = rank_s[t];
         for (int i = r - 1; i >= 0; --i) {
             cplx x = Vg[i + t * EIG_MAX];
             if (A) {
-                for (int k = i + 1; k < r; ++k) x = csub(x, cmul(eig_conj(Lg[k + i * EIG_MAX]), w[k]));
-                x = cscale(x, 1.0 / Lg[i + i * EIG_MAX].x);
+                for (int k = i + 1; k < r; ++k) x = csub(x, cmul(eig_conj(Lb[k + i * EIG_MAX]), Vg[k + t * EIG_MAX]));
+                x = cscale(x, 1.0 / Lb[i + i * EIG_MAX].x);
             }
-            w[i] = x;
+            Vg[i + t * EIG_MAX] = x;
+            Vout[i + (size_t)rank * ld] = x;
         }
-        for (int i = 0; i < r; ++i) Vout[i + (size_t)rank * ld] = w[i];
     }
 }
 
@@ -185,7 +234,20 @@ int fh_launch_herm_eig(int r, int ld, const cplx* S, const cplx* A, void* scratc
     cplx* Lg = (cplx*)scratch;
     cplx* Vg = Lg + EIG_MAX * EIG_MAX;
     double* rot = (double*)(Vg + EIG_MAX * EIG_MAX);
-    hipLaunchKernelGGL(k_herm_eig, dim3(1), dim3(EIG_THREADS), 0, st, r, ld, S, A, Lg, Vg, rot, flags, lambda, Vout, 30);
+    // one-time: ask for the large dynamic LDS allocation; fall back to the global-memory variant if refused
+    static int lds_mode = -1;
+    const size_t dyn = (size_t)2 * EIG_MAX * EIG_MAX * sizeof(cplx) + 32 * 4 * sizeof(double);
+    if (lds_mode < 0) {
+        lds_mode = 0;
+        if (!getenv("FH_EIG_NO_LDS") &&
+            hipFuncSetAttribute((const void*)k_herm_eig<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess)
+            lds_mode = 1;
+        (void)hipGetLastError();
+    }
+    if (lds_mode == 1)
+        hipLaunchKernelGGL((k_herm_eig<true>), dim3(1), dim3(EIG_THREADS), dyn, st, r, ld, S, A, Lg, Vg, rot, flags, lambda, Vout, 30);
+    else
+        hipLaunchKernelGGL((k_herm_eig<false>), dim3(1), dim3(EIG_THREADS), 0, st, r, ld, S, A, Lg, Vg, rot, flags, lambda, Vout, 30);
     return 0;
 }
 
