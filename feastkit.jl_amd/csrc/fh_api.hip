@@ -44,9 +44,10 @@ void fh_free_bufs(feasthip_ctx* h) {
     h->bufs.clear();
 }
 
-// Sampled event timing (1 launch in 8): every FH_PROF_PERIOD-th launch of a class is bracketed by two events
+// Sampled event timing (1 launch in 7: a period coprime to the iteration caps, so the samples do not alias with
+// the position inside a solve, where kernel durations shrink as nodes converge): every FH_PROF_PERIOD-th launch of a class is bracketed by two events
 // on the launch stream; the class average is (sum of sampled durations)/(samples).
-#define FH_PROF_PERIOD 8
+#define FH_PROF_PERIOD 7
 static thread_local int fh_prof_open = 0;
 void fh_prof_begin(feasthip_ctx* h, const char* cls) {
     fh_prof_open = 0;
