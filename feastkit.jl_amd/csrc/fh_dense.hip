@@ -9,6 +9,7 @@
 // Factors are N x N c128 column-major (LAPACK layout, so pivot search walks contiguous memory);
 // right-hand sides / solutions are row-major N x ld panels (fh_common.hpp), so a row
 // interchange moves one contiguous line and the triangular sweeps stream whole rows.
+#include <stdlib.h>
 #include "fh_common.hpp"
 #include "fh_kernels.hpp"
 #include "fh_dense.hpp"
@@ -119,8 +120,150 @@ __global__ __launch_bounds__(FH_BLOCK) void k_dense_op(fh_dense_op_args a) {
     }
 }
 
+// Plain products (dot_mode 0: project, Ritz residual, refinement residual) run on the f64 matrix
+// cores: one wave owns a 16-row band of the output and TPW 16-column tiles, the contraction is
+// staged in KC-deep chunks with the panel rows shared through LDS (split re/im, rows padded by
+// 16 doubles so the four k-rows of an operand read fall into different bank halves) and the matrix
+// operands taken straight from global memory (16 consecutive rows of one column = one 128/256 B
+// segment per 16 lanes).  Blocks are numbered so that the 8 consecutive ids that land on the 8 XCDs
+// carry 8 different row tiles and the blocks of one XCD walk the nodes of the same row tile, which
+// keeps the tile of A in that XCD's L2 while every node consumes it.
+typedef double dop_v4d __attribute__((ext_vector_type(4)));
+#define DOP_KC 16
+#define DOP_PAD 16
+
+template <typename VT, int LD, bool BIDENT, int TRB>
+__global__ __launch_bounds__(FH_BLOCK) void k_dense_op_mfma(fh_dense_op_args a, int row_tiles) {
+    constexpr int KC = DOP_KC, CT = LD / 16, NCG = 4 / TRB, TPW = CT / NCG, XPT = KC * LD / FH_BLOCK;
+    constexpr bool CPLX = sizeof(VT) == sizeof(cplx);
+    static_assert(TPW >= 1 && XPT >= 1, "tile split");
+    __shared__ double Xre[KC][LD + DOP_PAD];
+    __shared__ double Xim[KC][LD + DOP_PAD];
+    const int b = blockIdx.x;
+    const int rt = (b & 7) + 8 * ((b >> 3) / a.nodes);
+    const int node = (b >> 3) % a.nodes;
+    if (rt >= row_tiles) return;
+    if (a.node_active && a.node_active[node] == 0) return;
+    const int N = a.N;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int band = w % TRB, cg = w / TRB;
+    const int i0 = rt * (16 * TRB);
+    const int irow = i0 + 16 * band + lr;          // matrix row this lane feeds as MFMA A operand
+    const cplx* X = a.X + (size_t)node * a.x_node_stride;
+    cplx* Y = a.Y + (size_t)node * a.y_node_stride;
+    const VT* A = (const VT*)a.A;
+    const VT* B = (const VT*)a.B;
+    dop_v4d aR[TPW], aI[TPW], bR[BIDENT ? 1 : TPW], bI[BIDENT ? 1 : TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        aR[q] = dop_v4d{0, 0, 0, 0}; aI[q] = dop_v4d{0, 0, 0, 0};
+        if (!BIDENT) { bR[q] = dop_v4d{0, 0, 0, 0}; bI[q] = dop_v4d{0, 0, 0, 0}; }
+    }
+    cplx xn[XPT];
+    double are[KC / 4], aim[KC / 4], bre[KC / 4], bim[KC / 4];
+    auto load_chunk = [&](int j0) {
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int e = t + q * FH_BLOCK, jj = e / LD, c = e % LD;
+            xn[q] = (j0 + jj < N) ? X[(size_t)(j0 + jj) * LD + c] : cmake(0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            const int j = j0 + 4 * s + lk;
+            const bool ok = irow < N && j < N;
+            if constexpr (CPLX) {
+                cplx v = ok ? A[(size_t)j * N + irow] : cmake(0, 0);
+                are[s] = v.x; aim[s] = v.y;
+                if (!BIDENT) { cplx u = ok ? B[(size_t)j * N + irow] : cmake(0, 0); bre[s] = u.x; bim[s] = u.y; }
+            } else {
+                are[s] = ok ? A[(size_t)j * N + irow] : 0.0;
+                if (!BIDENT) bre[s] = ok ? B[(size_t)j * N + irow] : 0.0;
+            }
+        }
+    };
+    load_chunk(0);
+    for (int j0 = 0; j0 < N; j0 += KC) {
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int e = t + q * FH_BLOCK, jj = e / LD, c = e % LD;
+            Xre[jj][c] = xn[q].x; Xim[jj][c] = xn[q].y;
+        }
+        double cre[KC / 4], cim[KC / 4], dre[KC / 4], dim_[KC / 4];
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) { cre[s] = are[s]; cim[s] = aim[s]; dre[s] = bre[s]; dim_[s] = bim[s]; }
+        __syncthreads();
+        if (j0 + KC < N) load_chunk(j0 + KC);
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            double xr[TPW], xi[TPW];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                xr[q] = Xre[4 * s + lk][16 * (cg * TPW + q) + lr];
+                xi[q] = Xim[4 * s + lk][16 * (cg * TPW + q) + lr];
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) aR[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cre[s], xr[q], aR[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) aI[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cre[s], xi[q], aI[q], 0, 0, 0);
+            if constexpr (CPLX) {
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) aR[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cim[s], xi[q], aR[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) aI[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cim[s], xr[q], aI[q], 0, 0, 0);
+            }
+            if constexpr (!BIDENT) {
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) bR[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(dre[s], xr[q], bR[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) bI[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(dre[s], xi[q], bI[q], 0, 0, 0);
+                if constexpr (CPLX) {
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) bR[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-dim_[s], xi[q], bR[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) bI[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(dim_[s], xr[q], bI[q], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D layout of v_mfma_f64_16x16x4: register r of lane (lk, lr) is row lk + 4 r, column lr
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int c = 16 * (cg * TPW + q) + lr;
+        const cplx ca = a.coefA[node * LD + c], cb = a.coefB[node * LD + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 16 * band + lk + 4 * r;
+            if (i >= N) continue;
+            cplx y = cmul(ca, cmake(aR[q][r], aI[q][r]));
+            if (BIDENT) cfma(y, cb, X[(size_t)i * LD + c]); else cfma(y, cb, cmake(bR[q][r], bI[q][r]));
+            if (a.Bvec) y = csub(a.Bvec[(size_t)node * a.b_node_stride + (size_t)i * LD + c], y);
+            Y[(size_t)i * LD + c] = y;
+        }
+    }
+}
+
+template <typename VT, int LD, int TRB>
+static void launch_dense_op_mfma(const fh_dense_op_args& a, hipStream_t st) {
+    const int row_tiles = (a.N + 16 * TRB - 1) / (16 * TRB);
+    const int groups = (row_tiles + 7) / 8;
+    dim3 grid(8 * a.nodes * groups), block(FH_BLOCK);
+    if (a.B == nullptr) hipLaunchKernelGGL((k_dense_op_mfma<VT, LD, true, TRB>), grid, block, 0, st, a, row_tiles);
+    else hipLaunchKernelGGL((k_dense_op_mfma<VT, LD, false, TRB>), grid, block, 0, st, a, row_tiles);
+}
+
 template <typename VT, int LD>
 static void launch_dense_op_ld(const fh_dense_op_args& a, int nblk, hipStream_t st) {
+    static const bool no_mfma = getenv("FH_DENSE_OP_VALU") != nullptr;
+    if (a.dot_mode == 0 && !no_mfma) {
+        // 32-row tiles when 64-row tiles would leave CUs idle (single-node calls on mid-size matrices)
+        if constexpr (LD >= 32) {
+            if ((long)a.nodes * ((a.N + 63) / 64) < 256) { launch_dense_op_mfma<VT, LD, 2>(a, st); return; }
+        }
+        launch_dense_op_mfma<VT, LD, 4>(a, st);
+        return;
+    }
     dim3 grid(nblk, a.nodes), block(FH_BLOCK);
     if (a.B == nullptr) hipLaunchKernelGGL((k_dense_op<VT, LD, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_dense_op<VT, LD, false>), grid, block, 0, st, a);
