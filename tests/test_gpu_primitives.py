@@ -48,6 +48,23 @@ def test_spmm_matches_scipy(engine, N, m, cplx, bid):
     assert np.abs(YB - refB).max() <= 1e-12 * max(1.0, np.abs(refB).max())
 
 
+@pytest.mark.parametrize("N,m,cplx", [(777, 48, False), (1030, 64, True), (4100, 20, True)])
+def test_dense_matmul_nonsymmetric(engine, N, m, cplx):
+    """General (non-Hermitian) dense operands: a transposed or conjugated MFMA operand map would pass the
+    Hermitian cases below; N is no multiple of the 16/32/64-row tiles and 4100 rows take the 64-row path."""
+    rng = np.random.default_rng(N)
+    A = rng.standard_normal((N, N)) + (1j * rng.standard_normal((N, N)) if cplx else 0)
+    B = rng.standard_normal((N, N)) + (1j * rng.standard_normal((N, N)) if cplx else 0)
+    engine.set_problem(A, B)
+    X = rand_block(N, m, 8)
+    dX = engine.upload(X)
+    YA = engine.download(engine.matmul(0, dX, m))
+    YB = engine.download(engine.matmul(1, dX, m))
+    refA, refB = A @ X, B @ X
+    assert np.abs(YA - refA).max() <= 1e-12 * np.abs(refA).max()
+    assert np.abs(YB - refB).max() <= 1e-12 * np.abs(refB).max()
+
+
 @pytest.mark.parametrize("N,m", [(64, 4), (300, 16), (1000, 33), (515, 64)])
 @pytest.mark.parametrize("cplx,bid", [(False, False), (True, False), (False, True)])
 def test_dense_matmul(engine, N, m, cplx, bid):
