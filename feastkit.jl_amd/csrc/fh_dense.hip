@@ -896,6 +896,233 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_step(T* const* LUs, T* IN, T
     }
 }
 
+// Two-level substitution (default): the solve walks SOLVE_KB = 128 columns per step instead of 32.
+//   k_solve_diag    one workgroup per (column tile, node) keeps the 128 x 16 slab in LDS and runs the (up to)
+//                   four 32-block steps inside it: z_i = T_i^-1 s_i, then s_j -= M_ji z_i for the blocks still
+//                   to come -- the same products as k_solve_step, restricted to the 128 rows of the block;
+//   k_solve_update  rows outside the block:  IN[i,:] -= sum_{k<kd} M[i, K0+k] Z[K0+k,:], a k = 128 product:
+//                   one wave = a 16-row band x all active column tiles, the Z rows staged through LDS in
+//                   16-deep chunks (split re/im, padded, register prefetch), factor operands from global.
+// Against the 32-wide steps this rewrites the right-hand-side rows 4x less often and needs 2 launches per
+// 128 columns instead of 4.
+#define SOLVE_KB 128
+#define SOLVE_KC 16
+
+// IDENT: the right-hand side is the identity (grid = 8 column tiles x 128-blocks x nodes) and the result, the
+// inverse of the 128 x 128 diagonal block, goes behind the 32-block inverses (column-major, identity-padded):
+//   inv128 = LU + N*N + nblk32*2*32*32 + (2*block128 + upper)*128*128.
+// With it the per-step diagonal solve of the substitution is one product (k_solve_diag_inv).
+template <typename T>
+__host__ __device__ inline size_t lu_inv128_offset(int N) {
+    return (size_t)N * N + (size_t)((N + LU_NB - 1) / LU_NB) * 2 * LU_NB * LU_NB;
+}
+
+template <int LD, bool UPPER, bool IDENT, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T* OUT, size_t stride, int N, int K0, int kb) {
+    const int node = IDENT ? blockIdx.z : blockIdx.y;
+    const T* A = LUs[node];
+    const T* invbase = A + (size_t)N * N;
+    if (IDENT) { K0 = blockIdx.y * SOLVE_KB; kb = min(SOLVE_KB / LU_NB, (N - K0 + LU_NB - 1) / LU_NB); }
+    const T* in = IN + (size_t)node * stride;
+    T* out = OUT + (size_t)node * stride;
+    const int ta = blockIdx.x;
+    __shared__ T S[SOLVE_KB][17];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
+        const int i = e >> 4, c = e & 15, row = K0 + i;
+        if (IDENT) S[i][c] = LU_MK(i == 16 * ta + c ? 1.0 : 0.0, 0.0);
+        else S[i][c] = (i < LU_NB * kb && row < N) ? in[(size_t)row * LD + 16 * ta + c] : LU_MK(0, 0);
+    }
+    __syncthreads();
+    for (int step = 0; step < kb; ++step) {
+        const int i = UPPER ? kb - 1 - step : step;
+        const int k0 = K0 + LU_NB * i;
+        const T* inv = invbase + ((size_t)(k0 / LU_NB) * 2 + (UPPER ? 1 : 0)) * LU_NB * LU_NB;
+        typename lu_el<T>::v4 re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+        if (wave < 2) {
+#pragma unroll
+            for (int kk = 0; kk < LU_NB; kk += 4) {
+                const T a = inv[(size_t)(kk + lk) * LU_NB + 16 * wave + lr];
+                const T b = S[LU_NB * i + kk + lk][lr];
+                re = lu_el<T>::mfma(a.x, b.x, re);
+                re = lu_el<T>::mfma(-a.y, b.y, re);
+                im = lu_el<T>::mfma(a.x, b.y, im);
+                im = lu_el<T>::mfma(a.y, b.x, im);
+            }
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[LU_NB * i + 16 * wave + lu_el<T>::mrow(lk, r)][lr] = LU_MK(re[r], im[r]);
+        }
+        __syncthreads();
+        const int nj = UPPER ? i : kb - 1 - i;
+        for (int q = wave; q < 2 * nj; q += 4) {
+            const int j = UPPER ? q / 2 : i + 1 + q / 2;
+            const int rbase = LU_NB * j + 16 * (q & 1);
+            typename lu_el<T>::v4 ur = {0, 0, 0, 0}, ui = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < LU_NB; kk += 4) {
+                const int grow = K0 + rbase + lr, gcol = k0 + kk + lk;
+                const T a = (grow < N && gcol < N) ? A[(size_t)gcol * N + grow] : LU_MK(0, 0);
+                const T b = S[LU_NB * i + kk + lk][lr];
+                ur = lu_el<T>::mfma(a.x, b.x, ur);
+                ur = lu_el<T>::mfma(-a.y, b.y, ur);
+                ui = lu_el<T>::mfma(a.x, b.y, ui);
+                ui = lu_el<T>::mfma(a.y, b.x, ui);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                T& d = S[rbase + lu_el<T>::mrow(lk, r)][lr];
+                d = LU_MK(d.x - ur[r], d.y - ui[r]);
+            }
+        }
+        __syncthreads();
+    }
+    if (IDENT) {
+        T* inv128 = LUs[node] + lu_inv128_offset<T>(N) + ((size_t)blockIdx.y * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
+        for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
+            const int i = e & (SOLVE_KB - 1), c = e / SOLVE_KB;
+            inv128[(size_t)(16 * ta + c) * SOLVE_KB + i] = S[i][c];
+        }
+        return;
+    }
+    for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
+        const int i = e >> 4, c = e & 15, row = K0 + i;
+        if (i < LU_NB * kb && row < N) out[(size_t)row * LD + 16 * ta + c] = S[i][c];
+    }
+}
+
+// z = T128^-1 s for one 128-row slab and one 16-column tile per workgroup.  The triangular structure bounds the
+// contraction of output tile ti (lower: 16-blocks 0..ti; upper: ti..7); wave w takes the tiles w and 7 - w, nine
+// 16-blocks together for every wave, and issues all nine operand loads before the slab is even in LDS: the
+// kernel sits on the critical path of the substitution and is pure latency.
+template <int LD, bool UPPER, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag_inv(T* const* LUs, T* IN, T* OUT, size_t stride, int N, int K0, int kb) {
+    constexpr int NT = SOLVE_KB / 16;
+    const T* inv = LUs[blockIdx.y] + lu_inv128_offset<T>(N) + ((size_t)(K0 / SOLVE_KB) * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
+    const T* in = IN + (size_t)blockIdx.y * stride;
+    T* out = OUT + (size_t)blockIdx.y * stride;
+    const int ta = blockIdx.x;
+    __shared__ T S[SOLVE_KB][17];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int t0 = wave, t1 = NT - 1 - wave;
+    const int n0 = UPPER ? NT - t0 : t0 + 1;
+    const int blo0 = UPPER ? t0 : 0, blo1 = UPPER ? t1 : 0;
+    T a[NT + 1][4];
+#pragma unroll
+    for (int q = 0; q <= NT; ++q) {
+        const int tile = q < n0 ? t0 : t1, blk = q < n0 ? blo0 + q : blo1 + q - n0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) a[q][s4] = inv[(size_t)(16 * blk + 4 * s4 + lk) * SOLVE_KB + 16 * tile + lr];
+    }
+    for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
+        const int i = e >> 4, c = e & 15, row = K0 + i;
+        S[i][c] = (i < LU_NB * kb && row < N) ? in[(size_t)row * LD + 16 * ta + c] : LU_MK(0, 0);
+    }
+    __syncthreads();
+    typename lu_el<T>::v4 re0 = {0, 0, 0, 0}, im0 = {0, 0, 0, 0}, re1 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q <= NT; ++q) {
+        const int blk = q < n0 ? blo0 + q : blo1 + q - n0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const T b = S[16 * blk + 4 * s4 + lk][lr];
+            if (q < n0) {
+                re0 = lu_el<T>::mfma(a[q][s4].x, b.x, re0);
+                re0 = lu_el<T>::mfma(-a[q][s4].y, b.y, re0);
+                im0 = lu_el<T>::mfma(a[q][s4].x, b.y, im0);
+                im0 = lu_el<T>::mfma(a[q][s4].y, b.x, im0);
+            } else {
+                re1 = lu_el<T>::mfma(a[q][s4].x, b.x, re1);
+                re1 = lu_el<T>::mfma(-a[q][s4].y, b.y, re1);
+                im1 = lu_el<T>::mfma(a[q][s4].x, b.y, im1);
+                im1 = lu_el<T>::mfma(a[q][s4].y, b.x, im1);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i0 = 16 * t0 + lu_el<T>::mrow(lk, r), i1 = 16 * t1 + lu_el<T>::mrow(lk, r);
+        if (i0 < LU_NB * kb && K0 + i0 < N) out[(size_t)(K0 + i0) * LD + 16 * ta + lr] = LU_MK(re0[r], im0[r]);
+        if (i1 < LU_NB * kb && K0 + i1 < N) out[(size_t)(K0 + i1) * LD + 16 * ta + lr] = LU_MK(re1[r], im1[r]);
+    }
+}
+
+template <int LD, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_update(T* const* LUs, T* IN, const T* ZS, size_t stride, int N, int K0,
+                                                            int kd, int r0, int r1, int cta) {
+    typedef decltype(T().x) ET;
+    constexpr int KC = SOLVE_KC, CT = LD / 16, XPT = KC * LD / FH_BLOCK;
+    __shared__ ET Xre[KC][LD + 16];
+    __shared__ ET Xim[KC][LD + 16];
+    const T* A = LUs[blockIdx.y];
+    T* in = IN + (size_t)blockIdx.y * stride;
+    const T* zs = ZS + (size_t)blockIdx.y * stride;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ib = r0 + (blockIdx.x * 4 + wave) * 16;
+    const int irow = ib + lr;
+    typename lu_el<T>::v4 re[CT], im[CT];
+#pragma unroll
+    for (int q = 0; q < CT; ++q) { re[q] = typename lu_el<T>::v4{0, 0, 0, 0}; im[q] = typename lu_el<T>::v4{0, 0, 0, 0}; }
+    T xn[XPT], an[KC / 4];
+    auto load_chunk = [&](int j0) {
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int e = t + q * FH_BLOCK, jj = e / LD, c = e % LD;
+            const bool ok = j0 + jj < kd && K0 + j0 + jj < N;
+            xn[q] = ok ? zs[(size_t)(K0 + j0 + jj) * LD + c] : LU_MK(0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            const int jk = j0 + 4 * s + lk, col = K0 + jk;
+            an[s] = (irow < r1 && jk < kd && col < N) ? A[(size_t)col * N + irow] : LU_MK(0, 0);
+        }
+    };
+    load_chunk(0);
+    for (int j0 = 0; j0 < kd; j0 += KC) {
+#pragma unroll
+        for (int q = 0; q < XPT; ++q) {
+            const int e = t + q * FH_BLOCK, jj = e / LD, c = e % LD;
+            Xre[jj][c] = xn[q].x; Xim[jj][c] = xn[q].y;
+        }
+        T ac[KC / 4];
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) ac[s] = an[s];
+        __syncthreads();
+        if (j0 + KC < kd) load_chunk(j0 + KC);
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+#pragma unroll
+            for (int q = 0; q < CT; ++q) {
+                if (q >= cta) break;
+                const ET xr = Xre[4 * s + lk][16 * q + lr], xi = Xim[4 * s + lk][16 * q + lr];
+                re[q] = lu_el<T>::mfma(ac[s].x, xr, re[q]);
+                im[q] = lu_el<T>::mfma(ac[s].x, xi, im[q]);
+                re[q] = lu_el<T>::mfma(-ac[s].y, xi, re[q]);
+                im[q] = lu_el<T>::mfma(ac[s].y, xr, im[q]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < CT; ++q) {
+        if (q >= cta) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ib + lu_el<T>::mrow(lk, r);
+            if (i < r1) {
+                T* d = in + (size_t)i * LD + 16 * q + lr;
+                const T y = *d;
+                *d = LU_MK(y.x - re[q][r], y.y - im[q][r]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------
@@ -998,6 +1225,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     }
     fh_prof_begin(h, "lu_invert");
     hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, N);
+    {   // 128 x 128 inverses from the 32-block inverses: the in-block substitution applied to the identity
+        dim3 g(SOLVE_KB / 16, (N + SOLVE_KB - 1) / SOLVE_KB, nf);
+        hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dlus, (T*)nullptr, (T*)nullptr, (size_t)0, N, 0, 0);
+        hipLaunchKernelGGL((k_solve_diag<16, true, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dlus, (T*)nullptr, (T*)nullptr, (size_t)0, N, 0, 0);
+    }
     if (N <= 16000) hipLaunchKernelGGL(k_build_perm, dim3(nf), dim3(FH_BLOCK), (size_t)N * sizeof(int), h->stream, dpvs, N);
     else hipLaunchKernelGGL(k_build_perm_global, dim3(nf), dim3(64), 0, h->stream, dpvs, N);
     fh_prof_end(h);
@@ -1018,6 +1250,26 @@ template <int LD, typename T>
 static void lu_solve_launch(feasthip_ctx* h, T** dlus, T* Y, T* Z, size_t stride, int N, int nf, int m) {
     const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
     const int nblocks = (N + LU_NB - 1) / LU_NB;
+    static const bool one_level = getenv("FH_LU_SOLVE_32") != nullptr;
+    if (!one_level) {
+        const int nouter = (N + SOLVE_KB - 1) / SOLVE_KB;
+        for (int b = 0; b < nouter; ++b) {        // forward: L z = P b   (Y -> Z)
+            const int K0 = b * SOLVE_KB, kb = std::min(SOLVE_KB / LU_NB, (N - K0 + LU_NB - 1) / LU_NB);
+            const int r0 = K0 + LU_NB * kb;
+            hipLaunchKernelGGL((k_solve_diag_inv<LD, false, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, K0, kb);
+            if (r0 < N)
+                hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((N - r0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z,
+                                   stride, N, K0, LU_NB * kb, r0, N, cta);
+        }
+        for (int b = nouter - 1; b >= 0; --b) {   // backward: U x = z   (Z -> Y)
+            const int K0 = b * SOLVE_KB, kb = std::min(SOLVE_KB / LU_NB, (N - K0 + LU_NB - 1) / LU_NB);
+            hipLaunchKernelGGL((k_solve_diag_inv<LD, true, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, K0, kb);
+            if (K0 > 0)
+                hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((K0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y,
+                                   stride, N, K0, LU_NB * kb, 0, K0, cta);
+        }
+        return;
+    }
     for (int b = 0; b < nblocks; ++b) {        // forward: L z = P b   (Y -> Z)
         const int k0 = b * LU_NB, r0 = std::min(N, k0 + LU_NB);
         const int rb = lu_solve_rb(N - r0, nf);
@@ -1084,7 +1336,8 @@ static int lu_ensure_slots(feasthip_ctx* h, int nslots) {
         void* f = nullptr; int* pv = nullptr;
         // factor, then the inverted diagonal blocks (k_lu_invert_diag); pivots, then the row permutation
         const size_t nblk = (N + LU_NB - 1) / LU_NB;
-        FH_CHECK(hipMalloc(&f, (N * N + nblk * 2 * LU_NB * LU_NB) * esz));
+        const size_t nblk128 = (N + SOLVE_KB - 1) / SOLVE_KB;
+        FH_CHECK(hipMalloc(&f, (N * N + nblk * 2 * LU_NB * LU_NB + nblk128 * 2 * SOLVE_KB * SOLVE_KB) * esz));
         hipError_t e = hipMalloc((void**)&pv, 2 * N * sizeof(int));
         if (e != hipSuccess) { hipFree(f); h->last_error = "hipMalloc(pivots)"; return FEASTHIP_ERROR_MEMORY; }
         h->lu_factors.push_back(f); h->lu_pivots.push_back(pv); h->lu_valid.push_back(0); h->lu_z.push_back(cmake(0, 0));
