@@ -104,6 +104,8 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     if (!h) return FEASTHIP_ERROR_MEMORY;
     h->device = device_id;
     if (getenv("FH_LU_KB")) h->lu_outer_block = std::max(32, (atoi(getenv("FH_LU_KB")) / 32) * 32);
+    h->lu_solve_legacy = getenv("FH_LU_SOLVE_32") != nullptr;
+    h->lu_gemm_staged = getenv("FH_LU_GEMM_STAGED") != nullptr;
     h->sum_mode = getenv("FH_NO_SUM_MODE") ? 0 : 1;
     h->lu_panel_legacy = getenv("FH_LU_PANEL_LEGACY") ? atoi(getenv("FH_LU_PANEL_LEGACY")) : 0;
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }

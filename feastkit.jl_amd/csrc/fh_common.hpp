@@ -156,8 +156,10 @@ struct feasthip_ctx {
     std::vector<cplx> band_z;
     std::vector<int> col_mask;    // feasthip_set_column_mask: columns with 0 are not iterated by the Krylov solvers
     int sum_mode = 1;             // COCG contour_apply accumulates alpha*p into one shared panel (FH_NO_SUM_MODE=1 disables)
-    int lu_outer_block = 128;     // FH_LU_KB: outer block column of the two-level LU (multiple of 32)
+    int lu_outer_block = 0;       // FH_LU_KB: outer block column of the two-level LU (multiple of 32); 0 = by size (128, 256 from N = 6144)
     int lu_panel_legacy = 0;      // FH_LU_PANEL_LEGACY=1: per-column global-memory panel kernel
+    int lu_solve_legacy = 0;      // FH_LU_SOLVE_32=1: 32-column one-launch substitution steps (comparison)
+    int lu_gemm_staged = 0;       // FH_LU_GEMM_STAGED=1: trailing update with both panels through LDS (comparison; always for complex64)
 
     // host-mapped progress word written by the device: (chunk tag << 32) | active columns
     volatile unsigned long long* h_progress = nullptr;   // pinned host view

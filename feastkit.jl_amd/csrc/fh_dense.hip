@@ -644,7 +644,7 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, i
         for (int q = 0; q < PF; ++q) {
             const int e = t + q * FH_BLOCK;
             Ls[e / 64][e % 64] = pl[q];
-            Us[e % KC][e / KC] = pu[q];
+            Us[e % KC][(e / KC) ^ ((e % KC) & 15)] = pu[q];   // XOR swizzle: the transposed store hits 16 bank groups, not one
         }
     };
     auto mma = [&]() {
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, i
         for (int kk = 0; kk < KC; kk += 4) {
             T u[2], l[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) u[a] = Us[kk + lk][wc + 16 * a + lr];
+            for (int a = 0; a < 2; ++a) u[a] = Us[kk + lk][(wc + 16 * a + lr) ^ ((kk + lk) & 15)];
 #pragma unroll
             for (int b = 0; b < 2; ++b) l[b] = Ls[kk + lk][wi + 16 * b + lr];
             // four sweeps over the 2x2 tiles: dependent MFMAs on one accumulator are 8 issues apart
@@ -711,6 +711,103 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, i
                     A[(size_t)c * N + i] = v;
                 }
             }
+}
+
+// Second form of the trailing update (default): the L panel is no longer staged through LDS.  A wave owns 16
+// rows of the 64 x 64 tile and all four 16-column tiles: its L operand (16 consecutive rows of one factor column,
+// one 256 B segment per 16 lanes) comes straight from global memory, once per k-step, and is reused by the four
+// column tiles; only the U block -- whose contiguous direction (k) is the wrong one for an MFMA operand -- goes
+// through LDS (transposed, XOR-swizzled store).  Same transposed product and super-tile order as k_lu_gemm.
+template <int KC, typename T>
+__global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
+                                                              int c1, int TR, int TC) {
+    T* A = LUs[blockIdx.y];
+    __shared__ T Us[KC][64];
+    const int t = threadIdx.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int SR = (TR + 7) >> 3;
+    const int sw = min(8, TC);
+    const int st = (slot / (8 * sw)) * 8 + xcd, within = slot % (8 * sw);
+    const int tr = (st % SR) * 8 + (within & 7), tc = (st / SR) * sw + (within >> 3);
+    if (tr >= TR || tc >= TC) return;
+    const int i0 = r0 + tr * 64, cc0 = c0 + tc * 64;
+    const int lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int irow = i0 + 16 * wave + lr;
+    constexpr int PF = KC * 64 / FH_BLOCK;
+    T pu[PF], ln[KC / 4];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = t + q * FH_BLOCK;
+            const int ku = e % KC, cc = e / KC;
+            pu[q] = (cc0 + cc < c1) ? A[(size_t)(cc0 + cc) * N + k0 + kc + ku] : LU_MK(0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) ln[s] = (irow < r1) ? A[(size_t)(k0 + kc + 4 * s + lk) * N + irow] : LU_MK(0, 0);
+    };
+    fetch(0);
+    typename lu_el<T>::v4 re[4], im[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) { re[a] = (typename lu_el<T>::v4){0, 0, 0, 0}; im[a] = re[a]; }
+    T lc[KC / 4];
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int e = t + q * FH_BLOCK;
+            Us[e % KC][(e / KC) ^ ((e % KC) & 15)] = pu[q];
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) lc[s] = ln[s];
+    };
+    auto mma = [&]() {
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            T u[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) u[a] = Us[4 * s + lk][(16 * a + lr) ^ ((4 * s + lk) & 15)];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(u[a].x, lc[s].x, re[a]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].x, lc[s].y, im[a]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(-u[a].y, lc[s].y, re[a]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].y, lc[s].x, im[a]);
+        }
+    };
+    int kc = 0;
+    for (; kc + KC < kd; kc += KC) {
+        if (kc) __syncthreads();
+        stage();
+        __syncthreads();
+        fetch(kc + KC);
+        mma();
+    }
+    if (kc) __syncthreads();
+    stage();
+    __syncthreads();
+    T cv[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = cc0 + 16 * a + lu_el<T>::mrow(lk, r);
+            cv[a][r] = (irow < r1 && c < c1) ? A[(size_t)c * N + irow] : LU_MK(0, 0);
+        }
+    mma();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = cc0 + 16 * a + lu_el<T>::mrow(lk, r);
+            if (irow < r1 && c < c1) {
+                T v = cv[a][r];
+                v.x -= re[a][r];
+                v.y -= im[a][r];
+                A[(size_t)c * N + irow] = v;
+            }
+        }
 }
 
 // ---- solve ------------------------------------------------------------------------------
@@ -1187,10 +1284,16 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
         const int sw = std::min(8, TC);
         const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
-        hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), dim3(((nsuper + 7) / 8) * 8 * 8 * sw, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+        // measured on cfg 5: fp64 775 (staged) -> 756 ms (direct); complex64 432 (staged) vs 444 ms (direct)
+        const bool staged = h->lu_gemm_staged != 0;
+        const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nf);
+        if (staged || sizeof(T) != sizeof(cplx)) hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+        else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
         fh_prof_end(h);
     };
-    const int KB = h->lu_outer_block;
+    // measured (cfg 2 / cfg 5): at N = 4096 a 256-wide outer block is neutral, at N = 8192 it saves 4-6 % (the k = 256
+    // trailing product runs at 52 instead of 46 TFLOP/s and outweighs the longer k = 32 in-block updates)
+    const int KB = h->lu_outer_block > 0 ? h->lu_outer_block : (N >= 6144 ? 256 : 128);
     for (int K0 = 0; K0 < N; K0 += KB) {
         const int Kend = std::min(N, K0 + KB);
         for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
@@ -1250,7 +1353,7 @@ template <int LD, typename T>
 static void lu_solve_launch(feasthip_ctx* h, T** dlus, T* Y, T* Z, size_t stride, int N, int nf, int m) {
     const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
     const int nblocks = (N + LU_NB - 1) / LU_NB;
-    static const bool one_level = getenv("FH_LU_SOLVE_32") != nullptr;
+    const bool one_level = h->lu_solve_legacy != 0;
     if (!one_level) {
         const int nouter = (N + SOLVE_KB - 1) / SOLVE_KB;
         for (int b = 0; b < nouter; ++b) {        // forward: L z = P b   (Y -> Z)

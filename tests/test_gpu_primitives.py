@@ -197,6 +197,34 @@ def test_dense_lu_shifted_solve(engine, N, m, cplx, bid, prec):
     assert (np.linalg.norm(Sm @ Y - X, axis=0) / np.linalg.norm(X, axis=0)).max() < 1e-11
 
 
+@pytest.mark.parametrize("kb,legacy_solve", [(64, False), (256, False), (128, True)])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_dense_lu_block_widths(kb, legacy_solve, prec, monkeypatch):
+    """The outer block column of the two-level LU is chosen by size (128, 256 from N = 6144); the 256-wide path and
+    the 32-column substitution kept for comparison are run here on a small non-symmetric matrix whose size is no
+    multiple of any block width.  The environment is read when the handle is created."""
+    import feastkit_jl_amd as fk
+    monkeypatch.setenv("FH_LU_KB", str(kb))
+    if legacy_solve:
+        monkeypatch.setenv("FH_LU_SOLVE_32", "1")
+    eng = fk.HipEngine(0)
+    N, m = 839, 40
+    rng = np.random.default_rng(kb)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    eng.set_problem(A, None)
+    eng.set_solver("direct", factor_precision=prec)
+    z = 0.2 - 0.4j
+    X = rand_block(N, m, 9)
+    dY, rc = eng.shifted_solve(z, eng.upload(X), m)
+    assert rc == 0
+    Y = eng.download(dY)
+    Sm = z * np.eye(N) - A
+    assert (np.linalg.norm(Sm @ Y - X, axis=0) / np.linalg.norm(X, axis=0)).max() < 1e-10
+    ref = sla.lu_solve(sla.lu_factor(Sm), X)
+    assert np.abs(Y - ref).max() <= 1e-8 * np.abs(ref).max()
+    eng.close()
+
+
 def test_contour_apply_matches_oracle_sum(engine):
     # Q_proj = sum_e 2 w_e (z_e B - A)^{-1} B Q and the variant-B moments, dense LU path
     N, m = 120, 12
