@@ -230,6 +230,40 @@ def test_cfg3_full_size_properties(engine):
     assert np.abs(G / np.outer(d, d) - np.eye(44)).max() <= 1e-8
 
 
+def test_cfg2_full_size_properties(engine):
+    """BASELINE cfg 2 at full size (N=4096 dense real symmetric, 8 nodes, M0=32, batched LU): spectrum known by
+    construction (Householder reflection of a diagonal), residual and orthonormality recomputed on the host."""
+    N = 4096
+    A = fk.workloads.reflected_diagonal(0.01 * np.arange(N))
+    lo = 0.01 * (N // 4) - 0.005
+    want = 0.01 * np.arange(N // 4, N // 4 + 20)
+    r = fk.feast(A, None, (lo, lo + 0.2), M0=32, fpm=fpm_with(f2=8), engine=engine)
+    assert r.info == 0 and r.M == 20 and r.epsout <= 1e-12
+    assert np.abs(np.sort(r.lambda_) - want).max() <= 1e-10
+    assert not np.iscomplexobj(r.q)                       # real input -> real vectors, as feast_sygv! returns
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert res.max() <= 1e-10
+    assert np.abs(r.q.T @ r.q - np.eye(20)).max() <= 1e-10
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_cfg5_full_size_properties(engine, prec):
+    """BASELINE cfg 5 at full size (N=8192 complex non-Hermitian, circle centre 0 radius 2, 24 nodes, M0=48; prec 32 =
+    "ComplexF32 mixed precision": complex64 LU + fp64 refinement): eigenvalues known by construction, residual of
+    every returned pair recomputed on the host in fp64."""
+    A, delta = fk.workloads.disc_spectrum_general(8192)
+    A = np.asfortranarray(A)
+    inside = delta[np.abs(delta) <= 2.0]
+    r = fk.feast_general(A, None, 0.0, 2.0, M0=48, fpm=fpm_with(f8=24, f4=20), engine=engine, inner_precision=prec)
+    assert r.info == 0 and r.M == len(inside) == 28
+    key = lambda x: (round(x.real, 7), round(x.imag, 7))
+    assert np.abs(np.array(sorted(r.lambda_, key=key)) - np.array(sorted(inside, key=key))).max() <= 1e-10
+    assert r.epsout <= 1e-11
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert res.max() <= 1e-10
+    engine.set_solver("direct")           # back to fp64 factors for the tests that follow
+
+
 def test_cfg5_reduced_general_dense(engine):
     """cfg 5 shape at N=400: non-normal complex matrix with known eigenvalues in the disc."""
     N = 400
