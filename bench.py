@@ -123,7 +123,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.profile_reset()
-    eng.profile_enable(os.environ.get("FEAST_BENCH_NOPROF") is None)   # sampled HIP-event timing (1 launch in 7)
+    eng.profile_enable(os.environ.get("FEAST_BENCH_NOPROF") is None)   # sampled HIP-event timing (1 launch in 13)
     fence()
     t0 = time.perf_counter()
     results = [step() for _ in range(args.steps)]
@@ -155,7 +155,7 @@ def main():
     # candidates: the SpMM Y = (zB - A) X and the Krylov update kernel (x += a p, r -= a q, fused dots);
     # the one with the larger share of the timed region is reported, the other kept under
     # "roofline_other".  Algorithmic bytes come from device-side counters of active (node, column)
-    # work per launch; the average launch time from HIP events on the launch stream (1 launch in 7).
+    # work per launch; the average launch time from HIP events on the launch stream (1 launch in 13).
     N, nnz = A.shape[0], A.nnz
     upd_cls = "cocg_xr" if args.solver == "cocg" else "bicg_xr"
     # COCG runs in sum mode inside contour_apply: the update kernel reads R, Q and writes R (3 passes);

@@ -44,10 +44,10 @@ void fh_free_bufs(feasthip_ctx* h) {
     h->bufs.clear();
 }
 
-// Sampled event timing (1 launch in 7: a period coprime to the iteration caps, so the samples do not alias with
+// Sampled event timing (1 launch in 13: a period coprime to the iteration caps, so the samples do not alias with
 // the position inside a solve, where kernel durations shrink as nodes converge): every FH_PROF_PERIOD-th launch of a class is bracketed by two events
 // on the launch stream; the class average is (sum of sampled durations)/(samples).
-#define FH_PROF_PERIOD 7
+#define FH_PROF_PERIOD 13
 static thread_local int fh_prof_open = 0;
 void fh_prof_begin(feasthip_ctx* h, const char* cls) {
     fh_prof_open = 0;
@@ -58,8 +58,14 @@ void fh_prof_begin(feasthip_ctx* h, const char* cls) {
     if (h->pending_events.size() > 60000) return;
     fh_event_pair ep;
     ep.cls = cls;
-    if (hipEventCreate(&ep.a) != hipSuccess) return;
-    if (hipEventCreate(&ep.b) != hipSuccess) { hipEventDestroy(ep.a); return; }
+    // events are recycled through a pool: creating and destroying a pair per sample cost more than recording it
+    if (h->event_pool.size() >= 2) {
+        ep.a = h->event_pool.back(); h->event_pool.pop_back();
+        ep.b = h->event_pool.back(); h->event_pool.pop_back();
+    } else {
+        if (hipEventCreate(&ep.a) != hipSuccess) return;
+        if (hipEventCreate(&ep.b) != hipSuccess) { hipEventDestroy(ep.a); return; }
+    }
     hipEventRecord(ep.a, h->stream);
     h->pending_events.push_back(ep);
     fh_prof_open = 1;
@@ -79,8 +85,8 @@ void fh_prof_collect(feasthip_ctx* h) {
             pc.total_ms += ms;
             pc.launches += 1;
         }
-        hipEventDestroy(ep.a);
-        hipEventDestroy(ep.b);
+        if (h->event_pool.size() < 8192) { h->event_pool.push_back(ep.a); h->event_pool.push_back(ep.b); }
+        else { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     }
     h->pending_events.clear();
 }
@@ -150,6 +156,8 @@ extern "C" int feasthip_destroy(feasthip_handle h) {
     fh_free_problem(h);
     fh_free_bufs(h);
     if (h->d_counters) hipFree(h->d_counters);
+    for (auto& ep : h->pending_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     if (h->h_progress) hipHostFree((void*)h->h_progress);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;

@@ -170,6 +170,7 @@ struct feasthip_ctx {
     int profiling = 0;
     std::map<std::string, fh_prof_class> prof;
     std::vector<fh_event_pair> pending_events;
+    std::vector<hipEvent_t> event_pool;         // recycled profiling events
 };
 
 // workspace helper: returns a device buffer of at least `bytes`, reallocating if needed
