@@ -692,11 +692,18 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
         fh_launch_publish_progress(s.node_active, nodes, h->d_progress, tag, h->stream);
         // throttle: wait (by polling host memory) until the device has finished chunk tag-2
         unsigned st = 0, sc = 0;
-        for (;;) {
+        for (unsigned spins = 1;; ++spins) {
             progress(st, sc);
             if (st >= 1 && sc == 0) { all_done = true; break; }
             if (tag < 3 || st + 3 > tag) break;      // at most three chunks queued ahead of the device
             std::this_thread::sleep_for(std::chrono::microseconds(100));   // poll, do not burn the core
+            if ((spins & 2047u) == 0) {              // every ~0.2 s: a faulted queue never publishes; do not wait for it
+                const hipError_t q = hipStreamQuery(h->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                    h->last_error = std::string("device queue failed while iterating: ") + hipGetErrorString(q);
+                    return FEASTHIP_ERROR_INTERNAL;
+                }
+            }
         }
     }
     FH_CHECK(hipStreamSynchronize(h->stream));
