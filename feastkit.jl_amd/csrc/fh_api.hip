@@ -54,12 +54,14 @@ void fh_prof_begin(feasthip_ctx* h, const char* cls) {
     if (!h->profiling) return;
     fh_prof_class& pc = h->prof[cls];
     pc.launches += 1;
-    if ((pc.launches % FH_PROF_PERIOD) != 1 && FH_PROF_PERIOD > 1) return;
+    static const int period = getenv("FH_PROF_PERIOD") ? std::max(1, atoi(getenv("FH_PROF_PERIOD"))) : FH_PROF_PERIOD;
+    static const bool nopool = getenv("FH_PROF_NOPOOL") != nullptr;
+    if (period > 1 && (pc.launches % period) != 1) return;
     if (h->pending_events.size() > 60000) return;
     fh_event_pair ep;
     ep.cls = cls;
     // events are recycled through a pool: creating and destroying a pair per sample cost more than recording it
-    if (h->event_pool.size() >= 2) {
+    if (!nopool && h->event_pool.size() >= 2) {
         ep.a = h->event_pool.back(); h->event_pool.pop_back();
         ep.b = h->event_pool.back(); h->event_pool.pop_back();
     } else {

@@ -436,13 +436,19 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                 Us[i][w] = A[(size_t)(c0 + w) * N + k0 + i];
             }
             __syncthreads();
-            if (t < wact) {
-                for (int i = 1; i < pc; ++i) {
-                    T x = Us[i][t];
-                    for (int j = 0; j < i; ++j) x = csub(x, cmul(Lsm[i][j], Us[j][t]));
-                    Us[i][t] = x;
+            // forward substitution with one wave per sub-panel column (W <= 16 waves): lane = row of the block, the
+            // solved component is broadcast by shuffle and every later row updates itself -- pc short steps instead
+            // of pc^2/2 dependent operations of a single thread
+            if (wave < wact) {
+                T x = lane < pc ? Us[lane][wave] : LU_MK(0, 0);
+                for (int i = 0; i + 1 < pc; ++i) {
+                    const T xi = LU_MK(__shfl(x.x, i), __shfl(x.y, i));
+                    if (lane > i && lane < pc) x = csub(x, cmul(Lsm[lane][i], xi));
                 }
-                for (int i = 0; i < pc; ++i) A[(size_t)(c0 + t) * N + k0 + i] = Us[i][t];
+                if (lane < pc) {
+                    Us[lane][wave] = x;
+                    A[(size_t)(c0 + wave) * N + k0 + lane] = x;
+                }
             }
             __syncthreads();
         }
@@ -453,13 +459,36 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
 #pragma unroll
             for (int w = 0; w < W; ++w)
                 a[r][w] = (rows[r] >= c0 && rows[r] < N && w < wact) ? A[(size_t)(c0 + w) * N + rows[r]] : LU_MK(0, 0);
-        for (int p = 0; p < pc; ++p) {
+        // The loop is bound by the latency of these streaming loads of L, not by their bytes.  complex64 has the
+        // registers for two previous columns per step (pc is a multiple of W, so even); complex128 at 1024 threads
+        // (128 VGPRs) does not -- the two-column form spilled -- and keeps one column per step.
+        if constexpr (sizeof(T) == sizeof(cplxf) && R <= 4) {
+            for (int p = 0; p < pc; p += 2) {
+                T l0[R], l1[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (rows[r] >= c0 && rows[r] < N) {
-                    const T l = A[(size_t)(k0 + p) * N + rows[r]];
+                for (int r = 0; r < R; ++r) {
+                    const bool own = rows[r] >= c0 && rows[r] < N;
+                    l0[r] = own ? A[(size_t)(k0 + p) * N + rows[r]] : LU_MK(0, 0);
+                    l1[r] = own ? A[(size_t)(k0 + p + 1) * N + rows[r]] : LU_MK(0, 0);
+                }
 #pragma unroll
-                    for (int w = 0; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, Us[p][w]));
+                for (int r = 0; r < R; ++r) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        a[r][w] = csub(a[r][w], cmul(l0[r], Us[p][w]));
+                        a[r][w] = csub(a[r][w], cmul(l1[r], Us[p + 1][w]));
+                    }
+                }
+            }
+        } else {
+            for (int p = 0; p < pc; ++p) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (rows[r] >= c0 && rows[r] < N) {
+                        const T l = A[(size_t)(k0 + p) * N + rows[r]];
+#pragma unroll
+                        for (int w = 0; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, Us[p][w]));
+                    }
                 }
             }
         }
