@@ -85,8 +85,7 @@ def test_primitive_fuzz(engine, seed, trials):
                     rr = np.linalg.norm(Ad @ Xr[:, :M] - (Bd @ Xr[:, :M]) * lam[:M].real, axis=0) / np.maximum(np.abs(lam[:M]), 1.0)
                     check("ritz res " + tag, np.abs(res - rr).max() <= 1e-9 * (rr.max() + 1e-300), f"{np.abs(res-rr).max():.2e}")
         except Exception as ex:
-            fails += 1
-            print("EXC", tag, repr(ex)[:200], flush=True)
+            failures.append(f"exception {tag}: {ex!r}"[:300])
 
     eng.set_solver("direct")
     assert not failures, "\n".join(failures)
