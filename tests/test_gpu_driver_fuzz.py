@@ -1,0 +1,86 @@
+"""Randomised end-to-end parity of the variant-A driver against the oracle and against LAPACK: random real
+symmetric pencils (dense -> batched LU, banded CSR -> banded LU, general CSR -> COCG), random intervals holding
+1..12 eigenvalues, same start subspace on both sides.  Bar: same info / M as the oracle in every case; where the
+reference algorithm converges (most cases): eigenvalues within 1e-9 of scipy.linalg.eigh, refinement-loop count
+within one of the oracle's, residuals <= 1e-10 recomputed on the host; where it does not (a persistent spurious Ritz
+value, which variant A never removes): the same loop count and final epsout as the oracle."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+import feast_oracle as fo
+import feastkit_jl_amd as fk
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(rng):
+    kind = rng.choice(["dense", "banded", "csr"])
+    N = int(rng.integers(30, 260))
+    gen = bool(rng.integers(2))
+    if kind == "dense":
+        A = rng.standard_normal((N, N)); A = 0.5 * (A + A.T)
+        B = None
+        if gen:
+            B = rng.standard_normal((N, N)); B = B @ B.T / N + np.eye(N)
+        Ad, Bd = A, B
+    else:
+        bw = int(rng.integers(1, 4)) if kind == "banded" else None
+        if kind == "banded":
+            diags = [rng.standard_normal(N - d) for d in range(bw + 1)]
+            A = sp.diags([diags[0] + 3.0 * np.linspace(0, 1, N)] + diags[1:] + diags[1:], [0] + list(range(1, bw + 1)) + [-d for d in range(1, bw + 1)])
+        else:
+            R = sp.random(N, N, density=4.0 / N, random_state=int(rng.integers(1 << 30)))
+            A = R + R.T + sp.diags(3.0 * np.linspace(0, 1, N))
+        A = sp.csr_matrix(A)
+        B = sp.csr_matrix(sp.diags(1.0 + rng.random(N))) if gen else None
+        Ad, Bd = A.toarray(), (None if B is None else B.toarray())
+    lam = sla.eigh(Ad, Bd, eigvals_only=True)
+    spread = lam[-1] - lam[0]
+    for _ in range(50):
+        k = int(rng.integers(1, 13))
+        i0 = int(rng.integers(2, N - k - 2))
+        lo_gap, hi_gap = lam[i0] - lam[i0 - 1], lam[i0 + k] - lam[i0 + k - 1]
+        if min(lo_gap, hi_gap) > 2e-3 * spread:
+            break
+    else:
+        return None
+    Emin, Emax = 0.5 * (lam[i0 - 1] + lam[i0]), 0.5 * (lam[i0 + k - 1] + lam[i0 + k])
+    M0 = min(N, k + max(6, k))
+    return kind, A, B, Ad, Bd, lam[i0:i0 + k], float(Emin), float(Emax), M0
+
+
+@pytest.mark.parametrize("seed,cases", [(3, 8), (11, 8)])
+def test_driver_fuzz_vs_oracle(engine, seed, cases):
+    rng = np.random.default_rng(seed)
+    done = solved = 0
+    while done < cases:
+        c = _case(rng)
+        if c is None:
+            continue
+        kind, A, B, Ad, Bd, want, Emin, Emax, M0 = c
+        N = Ad.shape[0]
+        Q0 = fo.seeded_subspace(N, M0, seed=seed + done)
+        fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 40
+        kw = dict(solver="direct") if kind != "csr" else dict(solver="cocg", solver_tol=1e-13, solver_maxiter=5000)
+        got = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm, engine=engine, Q0=Q0, **kw)
+        ref = fo.feast_hermitian(Ad, Bd, Emin, Emax, M0, ne=8, fpm4=40, Q0=Q0, real_projection=True)
+        tag = f"seed={seed} case={done} kind={kind} N={N} gen={B is not None} k={len(want)} M0={M0}"
+        assert (got.info, got.M) == (ref.info, ref.M), tag
+        if ref.info == 0:
+            solved += 1
+            assert got.M == len(want), tag
+            scale = max(1.0, np.abs(want).max())
+            assert np.abs(np.sort(got.lambda_) - want).max() <= 1e-9 * scale, tag
+            assert np.abs(np.sort(ref.lam) - want).max() <= 1e-9 * scale, tag
+            assert abs(got.loop - ref.loop) <= 1, f"{tag}: loops {got.loop} vs {ref.loop}"
+            BX = got.q if Bd is None else Bd @ got.q
+            res = np.linalg.norm(Ad @ got.q - BX * got.lambda_, axis=0) / np.maximum(np.abs(got.lambda_), 1.0) / np.linalg.norm(got.q, axis=0)
+            assert res.max() <= 1e-10, f"{tag}: residual {res.max():.2e}"
+        else:
+            # the reference algorithm itself does not get there (a persistent spurious Ritz value inside the interval:
+            # variant A has no spurious-pair removal) -- the device path must fail the same way, loop for loop
+            assert got.loop == ref.loop and abs(got.epsout - ref.epsout) <= 1e-6 * ref.epsout, tag
+        done += 1
+    assert solved >= (3 * cases) // 4
