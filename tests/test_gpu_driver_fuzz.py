@@ -84,3 +84,67 @@ def test_driver_fuzz_vs_oracle(engine, seed, cases):
             assert got.loop == ref.loop and abs(got.epsout - ref.epsout) <= 1e-6 * ref.epsout, tag
         done += 1
     assert solved >= (3 * cases) // 4
+
+
+def _general_case(rng):
+    N = int(rng.integers(30, 200))
+    cplx = bool(rng.integers(2))
+    # non-normal matrix with a known spectrum: reflected upper-triangular with prescribed diagonal
+    rad = 4.0 * np.sqrt(rng.random(N))
+    delta = rad * np.exp(2j * np.pi * rng.random(N)) if cplx else np.sort(rng.standard_normal(N) * 2.0) + 0j
+    U = np.triu(rng.standard_normal((N, N)) + (1j * rng.standard_normal((N, N)) if cplx else 0), 1) / np.sqrt(N)
+    T = np.diag(delta) + 0.1 * U
+    v = rng.standard_normal(N) + (1j * rng.standard_normal(N) if cplx else 0)
+    v /= np.linalg.norm(v)
+    H = np.eye(N) - 2 * np.outer(v, v.conj())
+    A = H @ T @ H
+    if not cplx:
+        A = A.real
+    for _ in range(60):
+        c = delta[int(rng.integers(N))] + 0.05 * (rng.standard_normal() + 1j * rng.standard_normal())
+        r = float(0.2 + 1.0 * rng.random())
+        d = np.abs(delta - c)
+        k = int((d <= r).sum())
+        if 1 <= k <= 8 and np.abs(d - r).min() > 0.05 * r:      # nothing close to the circle
+            # variant C has no rank compression: with many guard columns the filtered block is numerically rank
+            # deficient and the reduced pencil (hence loop counts, spurious values) is decided by rounding on both
+            # sides -- two guard columns keep it well posed
+            return A, delta[d <= r], complex(c), r, min(N, k + 2)
+    return None
+
+
+@pytest.mark.parametrize("seed,cases", [(5, 6)])
+def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
+    """Variant C (feast_general, full circular contour, dense LU) on random non-normal matrices, real and complex,
+    both LU precisions: same info / M as the oracle, eigenvalues within 1e-9 of the prescribed ones."""
+    rng = np.random.default_rng(seed)
+    done = solved = 0
+    key = lambda x: (round(x.real, 6), round(x.imag, 6))
+    while done < cases:
+        c = _general_case(rng)
+        if c is None:
+            continue
+        A, want, Emid, r, M0 = c
+        N = A.shape[0]
+        # tolerance 1e-10: at the default 1e-12 these non-normal matrices sit on their rounding floor (residuals hover at
+        # 1e-12..5e-12 from loop 2 on) and the loop in which either side happens to dip below the threshold is noise
+        fpm = fk.feastinit(); fpm[8] = 16; fpm[4] = 40; fpm[3] = 10
+        ref = fo.feast_general(A, None, Emid, r, M0, ne=16, fpm3=10, fpm4=40)
+        for prec in (64, 32):
+            got = fk.feast_general(A, None, Emid, r, M0=M0, fpm=fpm, engine=engine, inner_precision=prec)
+            tag = f"seed={seed} case={done} N={N} complex={np.iscomplexobj(A)} k={len(want)} M0={M0} prec={prec}"
+            assert (got.info, got.M) == (ref.info, ref.M), tag
+            # grci returns info 0 also when it runs out of loops (src/kernel/feast_kernel.jl:896-948), so "converged"
+            # is read off the residual
+            if ref.epsout <= 1e-10:
+                assert got.M == len(want) and got.epsout <= 1e-10, tag
+                assert np.abs(np.array(sorted(got.lambda_, key=key)) - np.array(sorted(want, key=key))).max() <= 1e-9 * max(1.0, np.abs(want).max()), tag
+                # complex64 factors + refinement tied to the outer residual are inexact solves: one more loop of slack
+                assert abs(got.loop - ref.loop) <= (1 if prec == 64 else 2), f"{tag}: loops {got.loop} vs {ref.loop}"
+            elif prec == 64:
+                # the reference algorithm stalls (spurious value inside the circle): the device path stalls the same way
+                assert got.loop == ref.loop and abs(got.epsout - ref.epsout) <= 1e-3 * ref.epsout, tag
+        solved += ref.epsout <= 1e-10
+        done += 1
+    engine.set_solver("direct")
+    assert solved >= (2 * cases) // 3
