@@ -103,7 +103,8 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                         solver="direct", solver_tol=0.0,
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
-                        preloaded=False, node_assignment="block", inner_precision=64, column_groups=1):
+                        preloaded=False, node_assignment="block", inner_precision=64, column_groups=1,
+                        spurious_filter=True):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -188,6 +189,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                       restart=solver_restart, cache_factors=True)
     if inner_precision not in (32, 64):
         raise ValueError("inner_precision must be 32 or 64")
+    inexact = bool(iterative and warm_start and inner_rtol is not None and float(inner_rtol) > 10.0 * tol_value)
     if iterative and warm_start:
         # inexact-solve mode: every loop reduces the (warm-started) residual by inner_rtol
         rt = tol_value if inner_rtol is None else float(inner_rtol)
@@ -215,6 +217,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     lam_vec = np.zeros(M0)
     res_vec = np.zeros(M0)
     ritz_lambda = None
+    eps_hist, inner_cap = [], int(solver_maxiter)
     dX = None
     stats = {"setup_seconds": t_setup, "krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0,
              "solve_seconds": 0.0, "loops": [], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
@@ -322,6 +325,26 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
             break
         t_ = tick()
         dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+        n_spurious = 0
+        if inexact and spurious_filter and loop_idx >= 1 and M > 1:
+            # Inexact inner solves leave solver noise in the guard columns.  Its Ritz values are arbitrary; one that
+            # lands inside the interval has an O(1) residual that never contracts and would hold epsout up forever
+            # (variant A has no spurious-pair removal; with exact solves the guard columns are true eigen-directions
+            # and stay outside).  A pair is set aside when its relative residual is > 0.1 AND > 100x the smallest
+            # residual of the pairs inside: a true pair inside the interval sees a filter value >= 1/2 and contracts
+            # with the others, it cannot sit at 10 % while another pair is 100x ahead.  Set-aside pairs stay in the
+            # subspace and are re-examined every loop (measured on a random pencil: the ten true pairs contract by
+            # ~1e-2 per loop while one to three noise pairs stay at residual 1).
+            flag = (res > 0.1) & (res > 100.0 * float(res.min()))
+            n_spurious = int(flag.sum())
+            if 0 < n_spurious < M:
+                order = np.concatenate([np.nonzero(~flag)[0], np.nonzero(flag)[0], np.arange(M, rank_q)])
+                lam_sorted = lam_sorted[order]
+                V_sorted = np.asfortranarray(V_sorted[:, order])
+                M = M - n_spurious
+                dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+            else:
+                n_spurious = 0
         ph["ritz"] += tick() - t_
         lam_vec[:rank_q] = lam_sorted
         if M > 0:
@@ -330,13 +353,25 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         else:
             epsout = math.inf
         M_found = M
-        stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout,
-                               "krylov_iterations": st.get("krylov_iterations", 0)})
+        stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout, "set_aside": n_spurious,
+                               "krylov_iterations": st.get("krylov_iterations", 0),
+                               "res_inside": np.array(res[:M], dtype=float).copy() if M > 0 else np.zeros(0)})
         if M > 0 and epsout <= eps_tol:
             break
         if loop_idx == maxloop:
             info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
             break
+        if inexact:
+            # stagnation guard: the outer residual should contract by about inner_rtol per loop.  When it has not even
+            # halved over two loops the inner solves are not delivering (iteration cap too low for this matrix):
+            # double the cap (cfg 3 contracts by 0.03-0.1 per loop and never gets here)
+            eps_hist.append(epsout)
+            if len(eps_hist) >= 3 and eps_hist[-1] > 0.5 * eps_hist[-3] and inner_cap < 16 * solver_maxiter:
+                inner_cap *= 2
+                engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
+                                  factor_precision=inner_precision)
+                stats["inner_cap"] = inner_cap
+                eps_hist.clear()
         active = rank_q
         dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
         ritz_lambda = lam_sorted.copy()

@@ -148,3 +148,28 @@ def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
         done += 1
     engine.set_solver("direct")
     assert solved >= (2 * cases) // 3
+
+
+@pytest.mark.parametrize("seed,cases", [(21, 6)])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_inexact_mode_fuzz(engine, seed, cases, prec):
+    """The bench's mode (COCG, Ritz warm start, inner_rtol 3e-2, <= 100 iterations per loop; fp64 and complex64
+    correction panels) on random sparse symmetric pencils: no oracle counterpart for the loop count (inexact solves), so
+    the bar is the answer -- all eigenvalues of the interval to 1e-9, residuals <= 1e-10 recomputed on the host."""
+    rng = np.random.default_rng(seed)
+    done = 0
+    while done < cases:
+        c = _case(rng)
+        if c is None or c[0] == "dense":
+            continue
+        kind, A, B, Ad, Bd, want, Emin, Emax, M0 = c
+        fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 60
+        got = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm, engine=engine, solver="cocg", warm_start=True, inner_rtol=3e-2,
+                       solver_maxiter=100, inner_precision=prec)
+        tag = f"seed={seed} case={done} kind={kind} N={Ad.shape[0]} gen={B is not None} k={len(want)} M0={M0} prec={prec}"
+        assert got.info == 0 and got.M == len(want), f"{tag}: info {got.info} M {got.M} loop {got.loop} eps {got.epsout:.1e}"
+        assert np.abs(np.sort(got.lambda_) - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), tag
+        BX = got.q if Bd is None else Bd @ got.q
+        res = np.linalg.norm(Ad @ got.q - BX * got.lambda_, axis=0) / np.maximum(np.abs(got.lambda_), 1.0) / np.linalg.norm(got.q, axis=0)
+        assert res.max() <= 1e-10, f"{tag}: residual {res.max():.2e}"
+        done += 1
