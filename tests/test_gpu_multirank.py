@@ -66,3 +66,49 @@ def test_two_ranks_one_gpu_match_single_rank(engine, tmp_path):
         assert np.allclose(g0[off + 3: off + 3 + n], np.sort(one.lambda_), atol=1e-10)
     off = 3 * (3 + n)
     assert (int(g0[off]), int(g0[off + 1])) == (0, 3) and np.allclose(g0[off + 2: off + 5], [0.5, 1.0, 2.0], atol=1e-8)
+
+
+WORKER4 = r'''
+import os, sys
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, torch, torch.distributed as dist
+import feast_oracle as fo, feastkit_jl_amd as fk
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size={world})
+A, B, lam = fo.cfg3_problem(16, 12, 10)
+eng = fk.HipEngine(0)
+fpm = fk.feastinit(); fpm[2] = 16; fpm[4] = 40
+# the bench's settings: COCG in sum mode, Ritz warm start, inexact solves, balanced nodes, column groups by rule
+r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 64, fpm, solver="cocg", warm_start=True, inner_rtol=3e-2,
+                           solver_maxiter=100, node_assignment="balanced", column_groups="auto", real_projection=True)
+np.save(r"{out}/w%d.npy" % rank, np.array([r.info, r.M, r.epsout, r.loop] + list(np.sort(r.lambda_)), dtype=float))
+eng.close()
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_bench_layout_ranks_match_single_rank(engine, tmp_path, world):
+    """The layouts bench.py takes at N = 4 (1 node group x 4 column groups of 16 columns) and at an odd rank count
+    (3 node groups, no column split), with the bench's solver settings, on one card: every rank returns the
+    single-rank eigenvalues."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker4.py"
+    script.write_text(WORKER4.format(root=ROOT, port=port, out=str(tmp_path), world=world))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(world)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [np.load(tmp_path / f"w{r}.npy") for r in range(world)]
+    assert all(np.array_equal(res[0], x) for x in res[1:])
+    A, B, lam = fo.cfg3_problem(16, 12, 10)
+    inside = lam[(lam >= 0) & (lam <= 0.42)]
+    fpm = fk.feastinit(); fpm[2] = 16; fpm[4] = 40
+    one = fk.feast_hip_hermitian(engine, A, B, 0.0, 0.42, 64, fpm, solver="cocg", warm_start=True, inner_rtol=3e-2,
+                                 solver_maxiter=100, real_projection=True)
+    n = len(inside)
+    assert (int(res[0][0]), int(res[0][1])) == (0, n) == (one.info, one.M)
+    assert res[0][2] <= 1e-12 and abs(int(res[0][3]) - one.loop) <= 2
+    assert np.allclose(res[0][4:4 + n], inside, atol=1e-10)
+    assert np.allclose(res[0][4:4 + n], np.sort(one.lambda_), atol=1e-10)
