@@ -329,3 +329,44 @@ def test_banded_drivers_host_logic():
         fk.feast_hbev(Hb, 1, lo, hi, 10, fk.feastinit(), engine=OracleEngine(), solver="cholesky")
     with pytest.raises(ValueError):
         fk.feast_sbev(np.zeros((1, 5)), 2, 0.0, 1.0, 2, engine=OracleEngine())
+
+
+WORKER8 = r'''
+import os, sys
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, torch.distributed as dist
+import feast_oracle as fo, feastkit_jl_amd as fk
+from oracle_engine import OracleEngine
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=8)
+A, B, lam = fo.cfg3_problem(8, 6, 5)
+fpm = fk.feastinit(); fpm[2] = 16
+eng = OracleEngine()
+r = fk.feast_hip_hermitian(eng, A, B, 0.0, 1.2, 64, fpm, real_projection=True, solver='bicgstab', warm_start=False,
+                           node_assignment='balanced', column_groups='auto')
+# 8 ranks, M0 = 64: 2 node groups x 4 column groups of 16 columns (the layout bench.py --gpus 8 takes)
+assert eng.node_list == fk.balanced_contour_points(16, 2)[rank // 4], (rank, eng.node_list)
+np.save(r"{out}/e%d.npy" % rank, np.concatenate([[r.info, r.M, r.loop, r.epsout], np.sort(r.lambda_)]))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_eight_rank_gloo_bench_layout(tmp_path):
+    """The N = 8 layout of bench.py (2 node groups x 4 column groups, balanced node lists) on gloo with the CPU
+    engine mirror: all ranks agree and reproduce the single-process eigenvalues."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8.format(root=ROOT, port=port, out=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(8)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [np.load(tmp_path / f"e{r}.npy") for r in range(8)]
+    assert all(np.array_equal(res[0], x) for x in res[1:])
+    A, B, lam = fo.cfg3_problem(8, 6, 5)
+    inside = lam[(lam >= 0) & (lam <= 1.2)]
+    fpm = fk.feastinit(); fpm[2] = 16
+    one = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 1.2, 64, fpm, real_projection=True)
+    assert (int(res[0][0]), int(res[0][1])) == (one.info, one.M) == (0, len(inside)) and abs(int(res[0][2]) - one.loop) <= 1
+    assert np.allclose(res[0][4:4 + one.M], inside, atol=1e-10)
