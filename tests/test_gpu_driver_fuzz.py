@@ -15,9 +15,9 @@ import feastkit_jl_amd as fk
 pytestmark = pytest.mark.gpu
 
 
-def _case(rng):
+def _case(rng, kmin=1, kmax=12, Nmin=30, Nmax=260):
     kind = rng.choice(["dense", "banded", "csr"])
-    N = int(rng.integers(30, 260))
+    N = int(rng.integers(Nmin, Nmax))
     gen = bool(rng.integers(2))
     if kind == "dense":
         A = rng.standard_normal((N, N)); A = 0.5 * (A + A.T)
@@ -39,7 +39,7 @@ def _case(rng):
     lam = sla.eigh(Ad, Bd, eigvals_only=True)
     spread = lam[-1] - lam[0]
     for _ in range(50):
-        k = int(rng.integers(1, 13))
+        k = int(rng.integers(kmin, kmax + 1))
         i0 = int(rng.integers(2, N - k - 2))
         lo_gap, hi_gap = lam[i0] - lam[i0 - 1], lam[i0 + k] - lam[i0 + k - 1]
         if min(lo_gap, hi_gap) > 2e-3 * spread:
@@ -47,16 +47,17 @@ def _case(rng):
     else:
         return None
     Emin, Emax = 0.5 * (lam[i0 - 1] + lam[i0]), 0.5 * (lam[i0 + k - 1] + lam[i0 + k])
-    M0 = min(N, k + max(6, k))
+    M0 = min(N, k + (16 if kmin >= 40 else max(6, k)))
     return kind, A, B, Ad, Bd, lam[i0:i0 + k], float(Emin), float(Emax), M0
 
 
-@pytest.mark.parametrize("seed,cases", [(3, 8), (11, 8)])
-def test_driver_fuzz_vs_oracle(engine, seed, cases):
+@pytest.mark.parametrize("seed,cases,wide", [(3, 8, False), (11, 8, False), (17, 3, True)])
+def test_driver_fuzz_vs_oracle(engine, seed, cases, wide):
+    """wide: 50..90 eigenvalues inside and M0 = k + 16 > 64 -- the 64-column panel path of every primitive."""
     rng = np.random.default_rng(seed)
     done = solved = 0
     while done < cases:
-        c = _case(rng)
+        c = _case(rng, 50, 90, 240, 420) if wide else _case(rng)
         if c is None:
             continue
         kind, A, B, Ad, Bd, want, Emin, Emax, M0 = c
