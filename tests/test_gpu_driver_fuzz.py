@@ -174,3 +174,47 @@ def test_inexact_mode_fuzz(engine, seed, cases, prec):
         res = np.linalg.norm(Ad @ got.q - BX * got.lambda_, axis=0) / np.maximum(np.abs(got.lambda_), 1.0) / np.linalg.norm(got.q, axis=0)
         assert res.max() <= 1e-10, f"{tag}: residual {res.max():.2e}"
         done += 1
+
+
+@pytest.mark.parametrize("seed,cases", [(9, 5)])
+def test_complex_symmetric_driver_fuzz_vs_oracle(engine, seed, cases):
+    """Complex-symmetric sibling (A == A^T complex, bilinear projection, full contour, pivoted-QR compression) on random
+    dense matrices, standard and generalized: same info / M / loop count (within one) as the oracle, eigenvalues
+    within 1e-9 of numpy's."""
+    rng = np.random.default_rng(seed)
+    done = solved = 0
+    key = lambda x: (round(x.real, 6), round(x.imag, 6))
+    while done < cases:
+        N = int(rng.integers(30, 160))
+        d = 3.0 * np.sqrt(rng.random(N)) * np.exp(2j * np.pi * rng.random(N))
+        U = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+        A = np.diag(d) + 0.03 * (U + U.T) / np.sqrt(N)
+        B = None
+        if rng.integers(2):
+            V = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+            B = np.eye(N) + 0.02 * (V + V.T) / np.sqrt(N)
+        lam = np.linalg.eigvals(A if B is None else np.linalg.solve(B, A))
+        sel = None
+        for _ in range(60):
+            c = lam[int(rng.integers(N))] + 0.03 * (rng.standard_normal() + 1j * rng.standard_normal())
+            r = float(0.2 + 0.8 * rng.random())
+            dist = np.abs(lam - c)
+            k = int((dist <= r).sum())
+            if 1 <= k <= 8 and np.abs(dist - r).min() > 0.05 * r:
+                sel = (complex(c), r, lam[dist <= r], min(N, k + 6))
+                break
+        if sel is None:
+            continue
+        c, r, want, M0 = sel
+        fpm = fk.feastinit(); fpm[8] = 16; fpm[4] = 40; fpm[3] = 10
+        ref = fo.feast_complex_symmetric(A, B, c, r, M0, ne=16, fpm3=10, fpm4=40)
+        got = fk.feast_hip_complex_symmetric(engine, A, B, c, r, M0, fpm)
+        tag = f"seed={seed} case={done} N={N} gen={B is not None} k={len(want)} M0={M0}"
+        assert (got.info, got.M) == (ref.info, ref.M), tag
+        if ref.info == 0 and ref.epsout <= 1e-10:
+            solved += 1
+            assert got.M == len(want), tag
+            assert np.abs(np.array(sorted(got.lambda_, key=key)) - np.array(sorted(want, key=key))).max() <= 1e-9 * max(1.0, np.abs(want).max()), tag
+            assert abs(got.loop - ref.loop) <= 1, f"{tag}: loops {got.loop} vs {ref.loop}"
+        done += 1
+    assert solved >= (2 * cases) // 3

@@ -1,5 +1,5 @@
 """One-off larger runs of the driver-level fuzz tests (tests/test_gpu_driver_fuzz.py) with fresh seeds.
-Usage: python tools/driver_fuzz_campaign.py <hermitian|wide|general|inexact> [first_seed] [n_seeds] [cases_per_seed]"""
+Usage: python tools/driver_fuzz_campaign.py <hermitian|wide|general|csym|inexact> [first_seed] [n_seeds] [cases_per_seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -15,6 +15,8 @@ for seed in range(first, first + n):
     try:
         if which in ("hermitian", "wide"):
             t.test_driver_fuzz_vs_oracle(eng, seed, cases, which == "wide")
+        elif which == "csym":
+            t.test_complex_symmetric_driver_fuzz_vs_oracle(eng, seed, cases)
         elif which == "general":
             t.test_general_driver_fuzz_vs_oracle(eng, seed, cases)
         else:
