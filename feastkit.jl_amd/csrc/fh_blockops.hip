@@ -205,18 +205,28 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gram_mfma(const cplx* __restrict__
 #pragma unroll
     for (int t = 0; t < NS; ++t) { rr[t] = (v4d){0, 0, 0, 0}; ii[t] = rr[t]; ri[t] = rr[t]; ir[t] = rr[t]; }
 
-    for (int i0 = row_begin + sub * 4; i0 < row_end; i0 += 4 * SUB) {
-        const int i = i0 + lk;
-        cplx x = cmake(0, 0);
-        if (i < row_end) x = X[(size_t)i * LD + stripe * 16 + lc];
+    // four row groups per step with all their loads issued first (the loop was one load -> 16 MFMAs -> next load, i.e.
+    // bound by the load latency); the accumulation order per wave is unchanged, so results are bit-identical
+    constexpr int UG = 4;
+    for (int i0 = row_begin + sub * 4; i0 < row_end; i0 += 4 * SUB * UG) {
+        cplx x[UG], y[UG][NS];
 #pragma unroll
-        for (int t = 0; t < NS; ++t) {
-            cplx y = cmake(0, 0);
-            if (i < row_end) y = Y[(size_t)i * LD + t * 16 + lc];
-            rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.x, rr[t], 0, 0, 0);
-            ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, y.y, ii[t], 0, 0, 0);
-            ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.x, y.y, ri[t], 0, 0, 0);
-            ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x.y, y.x, ir[t], 0, 0, 0);
+        for (int u = 0; u < UG; ++u) {
+            const int i = i0 + u * 4 * SUB + lk;
+            const bool in = i < row_end;
+            x[u] = in ? X[(size_t)i * LD + stripe * 16 + lc] : cmake(0, 0);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) y[u][t] = in ? Y[(size_t)i * LD + t * 16 + lc] : cmake(0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].x, rr[t], 0, 0, 0);
+                ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, y[u][t].y, ii[t], 0, 0, 0);
+                ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].y, ri[t], 0, 0, 0);
+                ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, y[u][t].x, ir[t], 0, 0, 0);
+            }
         }
     }
     // partial layout: [block][sub][c2 (col-major G: c1 + LD*c2)] raw four-accumulator form
@@ -241,7 +251,18 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gram_reduce(const cplx* __restrict
     const int e = blockIdx.x * FH_BLOCK + threadIdx.x;
     if (e >= LD * LD) return;
     double rr = 0, ii = 0, ri = 0, ir = 0;
-    for (int s = 0; s < nslots; ++s) {
+    int s = 0;
+    for (; s + 8 <= nslots; s += 8) {            // eight slots' loads in flight, added in slot order
+        cplx a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const cplx* p = partial + (size_t)(s + q) * LD * LD * 2 + (size_t)e * 2;
+            a[q] = p[0]; b[q] = p[1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { rr += a[q].x; ii += a[q].y; ri += b[q].x; ir += b[q].y; }
+    }
+    for (; s < nslots; ++s) {
         const cplx* p = partial + (size_t)s * LD * LD * 2 + (size_t)e * 2;
         cplx a = p[0], b = p[1];
         rr += a.x; ii += a.y; ri += b.x; ir += b.y;
