@@ -5,6 +5,7 @@
 // Ritz back-transform X = Q V (src/dense/feast_dense.jl:287-290), column norms/scaling
 // (:301-305), and the rank-revealing orthonormalisation that stands in for
 // _feast_qr_compress! (src/core/feast_aux.jl:101-131).
+#include <stdlib.h>
 #include "fh_common.hpp"
 #include "fh_kernels.hpp"
 
@@ -320,7 +321,55 @@ __global__ __launch_bounds__(FH_BLOCK) void k_small_matmul(const cplx* __restric
         __syncthreads();
     }
 }
+// MFMA form (default): a wave owns one 16-column tile of the output and keeps its slice of V (ld x 16) in registers
+// as the B operand for the whole kernel; rows of Q go through LDS 16 at a time (coalesced load, read back as the A
+// operand), the product is written row-major in 256 B segments.  The VALU form above reads two LDS operands per
+// FMA and is LDS-bound (85 us for 50 000 x 64 against 25 us of HBM time).
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_small_matmul_mfma(const cplx* __restrict__ Q, const cplx* __restrict__ V,
+                                                                 int N, cplx* __restrict__ Xout) {
+    constexpr int NS = LD / 16, SUB = 4 / NS, RB = 16 * SUB, KS = LD / 4;
+    __shared__ cplx Qs[RB][LD + 1];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ct = wave % NS, sb = wave / NS;
+    cplx vB[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) vB[kk] = V[(size_t)(16 * ct + lr) * LD + 4 * kk + lk];     // V[k + LD*c]
+    for (int i0 = blockIdx.x * RB; i0 < N; i0 += gridDim.x * RB) {
+        for (int e = t; e < RB * LD; e += FH_BLOCK) {
+            const int r = e / LD, c = e % LD;
+            Qs[r][c] = (i0 + r < N) ? Q[(size_t)(i0 + r) * LD + c] : cmake(0, 0);
+        }
+        __syncthreads();
+        v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const cplx a = Qs[16 * sb + lr][4 * kk + lk];
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vB[kk].x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, vB[kk].y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vB[kk].y, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vB[kk].x, im, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 16 * sb + lk + 4 * r;
+            if (i < N) Xout[(size_t)i * LD + 16 * ct + lr] = cmake(re[r], im[r]);
+        }
+        __syncthreads();
+    }
+}
+
 void fh_launch_small_matmul(const cplx* Q, const cplx* V, int N, int ld, cplx* Xout, hipStream_t st) {
+    static const bool valu = getenv("FH_SMALL_MATMUL_VALU") != nullptr;
+    if (!valu) {
+        const int rb = 16 * (4 / (ld / 16));
+        const int nb = std::min((N + rb - 1) / rb, 2048);
+        if (ld == 16) hipLaunchKernelGGL((k_small_matmul_mfma<16>), dim3(nb), dim3(FH_BLOCK), 0, st, Q, V, N, Xout);
+        else if (ld == 32) hipLaunchKernelGGL((k_small_matmul_mfma<32>), dim3(nb), dim3(FH_BLOCK), 0, st, Q, V, N, Xout);
+        else hipLaunchKernelGGL((k_small_matmul_mfma<64>), dim3(nb), dim3(FH_BLOCK), 0, st, Q, V, N, Xout);
+        return;
+    }
     int rpb = FH_BLOCK / ld;
     int nblk = std::min((N + rpb - 1) / rpb, 2048);
     size_t shm = ((size_t)ld * ld + FH_BLOCK) * sizeof(cplx);
