@@ -1331,7 +1331,8 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
             {
                 const int nrows = N - k0;
                 const dim3 g(nf), b(LU_PANEL_THREADS);
-                if (h->lu_panel_legacy || nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                if (h->lu_panel_legacy || nrows > 16 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
                 else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
                 else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
                 else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);

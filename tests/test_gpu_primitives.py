@@ -225,6 +225,26 @@ def test_dense_lu_block_widths(kb, legacy_solve, prec, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("prec", [64, 32])
+def test_dense_lu_tall_panels(engine, prec):
+    """N > 8192: the first panels hold more than 8 x 1024 rows and take the 16-rows-per-thread panel kernel
+    (k_lu_panel_reg<16,1>) and the 256-wide outer block; checked through the residual of a shifted solve."""
+    N, m = 8500, 4
+    rng = np.random.default_rng(85)
+    A = (rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))) / np.sqrt(N)
+    A = np.asfortranarray(A)
+    engine.set_problem(A, None)
+    engine.set_solver("direct", factor_precision=prec)
+    z = 2.5 + 0.5j                                   # outside the unit-disc spectrum: well conditioned
+    X = rand_block(N, m, 3)
+    dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    engine.set_solver("direct")
+    assert rc == 0
+    Y = engine.download(dY)
+    R = z * Y - A @ Y - X
+    assert (np.linalg.norm(R, axis=0) / np.linalg.norm(X, axis=0)).max() < 1e-11
+
+
 def test_contour_apply_matches_oracle_sum(engine):
     # Q_proj = sum_e 2 w_e (z_e B - A)^{-1} B Q and the variant-B moments, dense LU path
     N, m = 120, 12
