@@ -1,6 +1,7 @@
 """cfg 2 at full size on one GPU: dense symmetric N=4096 (default), 8 Gauss nodes, M0=32, direct solves.
 Usage: python tools/run_cfg2.py [N]"""
 import sys, os, time
+os.environ.setdefault("FH_PROF_PERIOD", "1")   # time every launch: the classes of the dense path have few launches
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

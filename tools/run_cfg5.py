@@ -1,6 +1,7 @@
 """cfg 5 at full size on one GPU: complex non-Hermitian N=8192, centre 0 radius 2, 24 nodes, M0=48.
 Usage: python tools/run_cfg5.py [N] [ne] [64|32]"""
 import sys, os, time
+os.environ.setdefault("FH_PROF_PERIOD", "1")   # time every launch: the classes of the dense path have few launches
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
