@@ -171,6 +171,9 @@ struct feasthip_ctx {
     std::map<std::string, fh_prof_class> prof;
     std::vector<fh_event_pair> pending_events;
     std::vector<hipEvent_t> event_pool;         // recycled profiling events
+    int prof_mult = 1;                          // sampling period multiplier, raised when the host cost of sampling shows
+    double prof_host_s = 0.0;                   // host seconds spent recording / reading events since profile_enable
+    double prof_t0 = 0.0;                       // steady-clock seconds at profile_enable
 };
 
 // workspace helper: returns a device buffer of at least `bytes`, reallocating if needed
