@@ -8,21 +8,42 @@ outer tolerance 1e-12.  A "step" = one complete FEAST solve (all refinement loop
 max relative residual of the inside eigenpairs is <= 1e-12) with A and B resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Prints ONE JSON line on rank 0.  Multi-GPU: the 16 quadrature nodes are block-partitioned
-over the ranks (strong scaling: total work fixed) with one RCCL all-reduce of Q_proj per loop.
+N > 1 without WORLD_SIZE in the environment: bench.py launches its own ranks (a child
+`python -m torch.distributed.run --nproc-per-node N ... bench.py`, started BEFORE this process
+touches the GPU) and forwards the child's JSON line and exit code.  Inside a rank the
+quadrature nodes / right-hand-side columns are partitioned over the ranks (strong scaling:
+total work fixed); the per-loop sum of Q_proj is ONE packed RCCL all-reduce issued by the C ABI
+itself (feasthip_comm_init_rank / contour_apply).  torch.distributed (gloo) is only the
+control plane that ships RCCL's unique id.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s nominal
+MFMA_F64_PEAK_TFLOPS = 78.6    # dense fp64 matrix peak (v_mfma_f64_16x16x4_f64)
+EMIN, EMAX, M0, NE = 0.0, 0.1775, 64, 16
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: PMC traffic files record it, stale ones are not quoted."""
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "feastkit.jl_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            hsh.update(open(os.path.join(d, name), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def build_problem():
@@ -31,102 +52,207 @@ def build_problem():
     return fk.workloads.laplacian_3d_pencil(50, 40, 25, 0.1)
 
 
-def cpu_baseline(A, B, n_inside):
-    """Reference CPU path timed on the host cores of this box, on a bounded sample.
-
-    The reference's default for sparse input is a direct factorisation per node
-    (UMFPACK, src/sparse/feast_sparse.jl:339); the oracle restates it with SuperLU.
-    Sample: ONE of the 16 nodes (factor z B - A, then solve the 64 right-hand sides); the
-    whole solve is priced as 16 factorisations + 3 sweeps x 16 block solves.
-    """
+def cpu_baseline(A, B, inside, gpu_lambda):
+    """The reference CPU path, MEASURED on this box's host cores: one complete solve of the same problem by the
+    oracle's restatement of variant A with the reference's default sparse solver -- a direct factorisation of
+    z_e B - A per node, factors cached across refinement loops (src/sparse/feast_sparse.jl:334-342; UMFPACK there,
+    SuperLU here) -- on the reference's default contour (16 Gauss nodes, circle), real projection, tol 1e-12.
+    Second leg: the reference's ITERATIVE option (per-column GMRES(30), <= 500 iterations, tol 1e-12 from a zero guess,
+    src/sparse/feast_sparse.jl:164-203) on sample columns of the node next to the real axis."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
     import feast_oracle as fo
-    Zne, _ = fo.feast_contour(0.0, 0.1775, 16)
-    Q = fo.seeded_subspace(A.shape[0], 64)
-    rhs = np.ascontiguousarray(B @ Q)
-    # one core for real: SuperLU itself is serial, but its supernodal updates call the host BLAS, whose thread pool
-    # would otherwise spin on every core of the box ("cores": 1 below is what is actually used)
     from threadpoolctl import threadpool_limits
-    t_factor = t_solve = 0.0
-    sample_nodes = (0, 8, 15)                     # near-axis, middle and far node of the half contour
-    with threadpool_limits(limits=1):
-        for e in sample_nodes:
+    out = {"unit": "eigenpairs/s", "kind": "port", "cores": 1, "blas_threads": 1}
+    with threadpool_limits(limits=1):            # SuperLU is serial; its BLAS calls must not spin on every core
+        t0 = time.perf_counter()
+        ref = fo.feast_hermitian(A, B, EMIN, EMAX, M0, ne=NE, fpm4=20, real_projection=True)
+        dt = time.perf_counter() - t0
+        ok = ref.info == 0 and ref.M == len(inside)
+        out.update({"value": round(ref.M / dt, 4) if ok else 0.0, "seconds": round(dt, 2), "loops": int(ref.loop),
+                    "factorizations": int(ref.stats.get("factorizations", 0)), "eigenpairs": int(ref.M), "max_residual": float(ref.epsout),
+                    "sample": "the WHOLE solve, not a sample: 16 SuperLU factorisations (MMD_AT_PLUS_A, symmetric mode; the reference "
+                              "uses UMFPACK) + %d sweeps of 16 x 64-RHS solves + QR/Rayleigh-Ritz/residuals, one core, one BLAS thread, "
+                              "%.1f s measured" % (ref.loop + 1, dt)})
+        if ok and gpu_lambda is not None and len(gpu_lambda) == ref.M:
+            out["parity_vs_cpu"] = {"max_abs_eigenvalue_diff": float(np.abs(np.sort(gpu_lambda) - np.sort(ref.lam)).max()),
+                                    "cpu_max_eigenvalue_error_vs_closed_form": float(np.abs(np.sort(ref.lam) - inside).max())}
+        # leg (ii): the reference's iterative option on 4 sample columns of the node nearest to the axis at Emax
+        Zne, _ = fo.feast_contour(EMIN, EMAX, NE)
+        e = int(np.argmax(Zne.real))
+        z = Zne[e]
+        Q = fo.seeded_subspace(A.shape[0], M0)[:, :4]
+        rhs = np.ascontiguousarray(B @ Q)
+        Ac, Bc = A.astype(np.complex128), B.astype(np.complex128)
+        mv = lambda x: z * (Bc @ x) - Ac @ x
+        t0 = time.perf_counter()
+        worst, its = 0.0, 0
+        for c in range(rhs.shape[1]):
+            x, _, n_it = fo.gmres_restarted(mv, rhs[:, c], 1e-12, 1e-12, 500, 30)
+            its += n_it
+            worst = max(worst, float(np.linalg.norm(rhs[:, c] - mv(x)) / np.linalg.norm(rhs[:, c])))
+        out["iterative_leg"] = {"method": "per-column GMRES(30), <= 500 iterations, rtol = atol = 1e-12, zero guess (reference defaults)",
+                                "node": "z = %.5f%+.5fi" % (z.real, z.imag), "columns": int(rhs.shape[1]), "iterations": int(its),
+                                "seconds": round(time.perf_counter() - t0, 2), "worst_relative_residual": worst,
+                                "converged_to_1e-12": bool(worst <= 1e-11),
+                                "note": "the reference's iterative path returns info=5 on this node; only its direct path solves cfg 3"}
+    return out
+
+
+def dense_configs(fk, eng):
+    """cfg 2 and cfg 5 (BASELINE.json configs[1], configs[4]) on this GPU, timed here: seconds per complete solve,
+    eigenpairs/s, host-recomputed residual and the MFMA roofline of the LU trailing update from the in-library timers."""
+    import numpy as np
+    out = {}
+    eng.profile_set_period(1)                     # few, very different launches per class: time every one
+
+    def mfma(seconds_cls="lu_gemm"):
+        ms, n = eng.profile_get(seconds_cls)
+        work = eng.profile_get_work(seconds_cls)
+        if not (n and ms > 0):
+            return None
+        tf = work / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "k_lu_gemm_direct / k_lu_gemm (trailing update of the batched LU)", "achieved": round(tf, 2),
+                "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TFLOPS, 4), "launches": int(n),
+                "total_ms": round(ms, 2), "flop": work}
+
+    def classes():
+        d = {}
+        for cls in ("lu_form", "lu_panel", "lu_laswp", "lu_trsm", "lu_gemm_in", "lu_gemm", "lu_invert", "lu_solve", "dense_op", "ortho", "gram"):
+            ms, n = eng.profile_get(cls)
+            if n:
+                d[cls] = {"launches": int(n), "total_ms": round(ms, 2)}
+        return d
+
+    # ---- cfg 2: N = 4096 dense real symmetric, 8 nodes, M0 = 32 ------------------------------------------------
+    N = 4096
+    A = np.asfortranarray(fk.workloads.reflected_diagonal(0.01 * np.arange(N)))    # column-major like a Julia Matrix
+    lo = 0.01 * (N // 4) - 0.005
+    want = 0.01 * np.arange(N // 4, N // 4 + 20)
+    best, r = 1e9, None
+    for rep in range(3):
+        fpm = fk.feastinit(); fpm[2] = 8
+        eng.profile_reset(); eng.profile_enable(rep == 2)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        r = fk.feast_hip_hermitian(eng, A, None, lo, lo + 0.2, 32, fpm, solver="direct")
+        eng.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    eng.profile_enable(False)
+    ok = r.info == 0 and r.M == 20
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0) if ok else [np.nan]
+    out["dense_cfg2"] = {"workload": "cfg2: N=4096 dense real symmetric, 8 Gauss nodes, M0=32, batched complex128 LU (upload of A inside the time)",
+                         "seconds": round(best, 4), "value": round(r.M / best, 2) if ok else 0.0, "unit": "eigenpairs/s", "eigenpairs": int(r.M),
+                         "loops": int(r.loop), "max_residual": float(np.max(res)),
+                         "max_eigenvalue_error": float(np.abs(np.sort(r.lambda_) - want).max()) if ok else None,
+                         "dtype": "f64", "roofline": mfma(), "kernel_classes": classes()}
+    del A
+    # ---- cfg 5: N = 8192 complex general, 24 nodes, M0 = 48 ------------------------------------------------------
+    A, delta = fk.workloads.disc_spectrum_general(8192)
+    A = np.asfortranarray(A)
+    inside = delta[np.abs(delta) <= 2.0]
+    key = lambda x: (round(x.real, 7), round(x.imag, 7))
+    for tag, prec in (("dense_cfg5", 64), ("dense_cfg5_mixed", 32)):
+        best, r = 1e9, None
+        for rep in range(2):
+            fpm = fk.feastinit(); fpm[8] = 24; fpm[4] = 20
+            eng.profile_reset(); eng.profile_enable(rep == 1)
+            eng.synchronize()
             t0 = time.perf_counter()
-            # symmetric-pattern minimum-degree ordering: the closest SuperLU analogue of UMFPACK's
-            # symmetric (AMD) strategy; COLAMD would cost 3x the fill on this pattern
-            lu = spla.splu(sp.csc_matrix(Zne[e] * B - A), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.1,
-                           options=dict(SymmetricMode=True))
-            t_factor += time.perf_counter() - t0
-            t0 = time.perf_counter()
-            lu.solve(rhs)
-            t_solve += time.perf_counter() - t0
-            del lu
-    t_factor /= len(sample_nodes); t_solve /= len(sample_nodes)
-    sweeps = 3
-    total = 16 * t_factor + sweeps * 16 * t_solve
-    return {"value": n_inside / total, "unit": "eigenpairs/s", "cores": 1, "kind": "port",
-            "sample": ("3 of 16 nodes (one BLAS thread): SuperLU (MMD_AT_PLUS_A, symmetric mode) factor %.1fs + 64-RHS solve %.1fs per node "
-                       "(oracle restatement of the reference's UMFPACK path, factors cached); full solve priced as 16 factors + %d sweeps x 16 "
-                       "solves = %.0fs" % (t_factor, t_solve, sweeps, total))}
+            r = fk.feast_hip_general(eng, A, None, 0.0, 2.0, 48, fpm, inner_precision=prec)
+            eng.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        eng.profile_enable(False)
+        ok = r.info == 0 and r.M == len(inside)
+        res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0) if ok else [np.nan]
+        err = float(np.abs(np.array(sorted(r.lambda_, key=key)) - np.array(sorted(inside, key=key))).max()) if ok else None
+        roof = mfma()
+        if roof and prec == 32:
+            roof["peak"] = 157.3; roof["frac"] = round(roof["achieved"] / 157.3, 4)      # dense fp32 matrix peak
+            roof["kernel"] += " on v_mfma_f32_16x16x4_f32"
+        out[tag] = {"workload": "cfg5: N=8192 dense ComplexF64 general, circle centre 0 radius 2, 24 nodes, M0=48, one GPU"
+                                + (", complex64 LU factors + fp64 refinement" if prec == 32 else ", complex128 LU"),
+                    "seconds": round(best, 4), "value": round(r.M / best, 2) if ok else 0.0, "unit": "eigenpairs/s", "eigenpairs": int(r.M),
+                    "expected_eigenpairs": int(len(inside)), "loops": int(r.loop), "max_residual": float(np.max(res)),
+                    "max_eigenvalue_error": err, "dtype": "f64" if prec == 64 else "f32 factors + f64 refinement",
+                    "roofline": roof, "kernel_classes": classes()}
+    eng.profile_set_period(0)
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--inner-rtol", type=float, default=3e-2)
-    ap.add_argument("--maxit", type=int, default=100)
+    ap.add_argument("--maxit", type=int, default=50)
     ap.add_argument("--solver", default="cocg", choices=["cocg", "bicgstab"])
+    ap.add_argument("--contour", default="gauss", choices=["gauss", "trapezoid", "zolotarev"], help="fpm[16]")
+    ap.add_argument("--aspect", type=int, default=4000, help="fpm[18]: ellipse ratio a/b x 100 (100 = the reference's default circle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the cfg 2 / cfg 5 dense measurements after the headline")
+    ap.add_argument("--no-default-contour", action="store_true", help="skip the secondary run on the reference's default contour")
     ap.add_argument("--reduced-solver", default="host", choices=["host", "device"])
-    ap.add_argument("--freeze-guards-after", type=int, default=-1,
-                    help="loop index after which guard columns (Ritz value outside the interval) are no longer iterated; -1 = never")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launch our own ranks; nothing in this process has touched the GPU yet (no torch import, no HIP call)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = [ln for ln in child.stdout.splitlines() if ln.startswith('{"metric"')]
+        for ln in child.stdout.splitlines():
+            if not ln.startswith('{"metric"'):
+                print(ln, file=sys.stderr)
+        if line:
+            print(line[-1])
+        sys.exit(child.returncode if child.returncode else (0 if line else 1))
 
     import numpy as np
     import torch
-    import torch.distributed as dist
     import feastkit_jl_amd as fk
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal on a one-GPU box: FEAST_BENCH_BACKEND=gloo lets several ranks share device 0
-    backend = os.environ.get("FEAST_BENCH_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    device = local_rank % ndev                     # fewer GPUs than ranks (rehearsal on one card): ranks share a device
+    torch.cuda.set_device(device)
+    eng = fk.HipEngine(device)
     if world > 1:
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")            # control plane only: carries RCCL's unique id
+        eng.comm_init_from_group(None)             # data plane: RCCL inside the C ABI (shared-device transport if ranks share a GPU)
     if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
     A, B, lam_exact = build_problem()
-    Emin, Emax, M0 = 0.0, 0.1775, 64
-    inside = lam_exact[(lam_exact >= Emin) & (lam_exact <= Emax)]
-    eng = fk.HipEngine(local_rank)
+    inside = lam_exact[(lam_exact >= EMIN) & (lam_exact <= EMAX)]
     eng.set_problem(A, B)                     # one-time upload, outside the timed region
     Q0_dev = eng.upload(fk.seeded_subspace(A.shape[0], M0))   # initial subspace (an input) resident in HBM
+    fpm16 = {"gauss": 0, "trapezoid": 1, "zolotarev": 2}[args.contour]
 
-    def step(precision=64):
+    def step(precision=64, aspect=args.aspect, f16=fpm16, maxit=args.maxit):
         fpm = fk.feastinit()
-        fpm[2], fpm[4] = 16, 40
-        return fk.feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=args.solver, warm_start=True,
-                                      inner_rtol=args.inner_rtol, solver_maxiter=args.maxit, preloaded=True,
+        fpm[2], fpm[4], fpm[16], fpm[18] = NE, 40, f16, aspect
+        return fk.feast_hip_hermitian(eng, A, B, EMIN, EMAX, M0, fpm, solver=args.solver, warm_start=True,
+                                      inner_rtol=args.inner_rtol, solver_maxiter=maxit, preloaded=True,
                                       node_assignment="balanced", inner_precision=precision, column_groups="auto",
-                                      Q0=Q0_dev, real_projection=True, reduced_solver=args.reduced_solver,
-                                      freeze_guards_after=None if args.freeze_guards_after < 0 else args.freeze_guards_after)
+                                      Q0=Q0_dev, real_projection=True, reduced_solver=args.reduced_solver)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        eng.barrier()                         # library all-reduce over the communicator (no-op at N = 1)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -139,18 +265,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     eng.profile_enable(False)
-    # secondary, untimed-for-`value` measurement: same solve with complex64 Krylov corrections
-    # (fp64 warm start / residual / Rayleigh-Ritz; identical converged eigenpairs)
-    step(32)
-    fence()
-    t1 = time.perf_counter()
-    mixed = step(32)
-    fence()
-    mixed_elapsed = time.perf_counter() - t1
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = eng.max_over_ranks(elapsed)
 
     res = results[-1]
     ok = all(r.info == 0 and r.M == len(inside) for r in results)
@@ -161,20 +276,22 @@ def main():
     value = (sum(r.M for r in results) / elapsed) if ok else 0.0
 
     # ---- roofline of the dominant kernel ---------------------------------------------------------
-    # candidates: the SpMM Y = (zB - A) X and the Krylov update kernel (x += a p, r -= a q, fused dots);
-    # the one with the larger share of the timed region is reported, the other kept under
-    # "roofline_other".  Algorithmic bytes come from device-side counters of active (node, column)
-    # work per launch; the average launch time from HIP events on the launch stream (1 launch in 13).
+    # candidates: the SpMM Y = (zB - A) X, the residual update (r -= a q, fused dots) and the direction/accumulator
+    # kernel; the one with the largest share of the timed region is reported, the others kept under
+    # "roofline_other".  Algorithmic bytes come from device-side counters of active (node, column) work per launch;
+    # the average launch time from HIP events on the launch stream (1 launch in 13).
     N, nnz = A.shape[0], A.nnz
-    upd_cls = "cocg_xr" if args.solver == "cocg" else "bicg_xr"
-    # COCG runs in sum mode inside contour_apply: the update kernel reads R, Q and writes R (3 passes);
-    # the solution panels are replaced by one shared accumulator handled in k_cocg_p_sum
-    upd_passes = 3 if args.solver == "cocg" else 7
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["kernels"]
-    except Exception:
-        pass
+    src_hash = kernel_source_hash()
+    pmc, pmc_file = {}, None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("pmc_traffic.json"):
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+            except Exception:
+                continue
+            if rec.get("kernel_source_hash") == src_hash:       # HBM counters of THIS tree's kernels only
+                pmc, pmc_file = rec["kernels"], name
+                break
 
     def roof(cls, kernel, alg_bytes):
         total_ms, launches = eng.profile_get(cls)
@@ -183,12 +300,13 @@ def main():
         avg_ms = total_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
         traffic = None
-        for name, rec in pmc.items():          # HBM bytes per launch from the committed PMC passes of this command
+        for name, rec in pmc.items():
             if name.replace(" ", "").startswith("void" + kernel.split("<")[0]) and ("cplx," in name or "<cplx" in name) and "cplxf" not in name:
                 traffic = rec["mean_hbm_bytes_per_launch"]
         return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same command)" if traffic else None,
+                "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources %s)"
+                                   % (pmc_file, src_hash)) if traffic else None,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes / launches),
                 "share_of_step": round(total_ms / (1e3 * elapsed), 3)}
 
@@ -196,41 +314,84 @@ def main():
     _, col_passes = eng.profile_get("spmm.column_passes")
     _, upd_cols = eng.profile_get("update.active_columns")
     matrix_bytes = nnz * (4 + 8 + 8) + 4 * (N + 1)            # col idx + A,B values (f64) + row pointers
-    r_spmm = roof("spmm", "k_spmm<cplx,double,64,false>", node_launches * matrix_bytes + col_passes * N * 16)
-    r_upd = roof(upd_cls, "k_cocg_update<cplx,64>" if args.solver == "cocg" else "k_xr_update<cplx,64>", upd_cols * upd_passes * N * 16)
-    cands = [r for r in (r_spmm, r_upd) if r]
-    cands.sort(key=lambda r: -r["share_of_step"])
-    roofline = cands[0] if cands else None
-    roofline_other = cands[1] if len(cands) > 1 else None
+    cands = [roof("spmm", "k_spmm<cplx,double,64,false>", node_launches * matrix_bytes + col_passes * N * 16)]
+    if args.solver == "cocg":
+        _, p_launches = eng.profile_get("cocg_p")
+        cands.append(roof("cocg_xr", "k_cocg_update<cplx,64>", upd_cols * 3 * N * 16))
+        # direction update P = R + beta P (3 passes per active column) + the shared accumulator (read + write per launch)
+        cands.append(roof("cocg_p", "k_cocg_p_sum<cplx,64>", upd_cols * 3 * N * 16 + p_launches * 2 * N * 64 * 16))
+    else:
+        cands.append(roof("bicg_xr", "k_xr_update<cplx,64>", upd_cols * 7 * N * 16))
+    cands = sorted([r for r in cands if r], key=lambda r: -r["share_of_step"])
     classes = {}
-    for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz", "reduced_eig"):
+    for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz",
+                "reduced_eig", "allreduce"):
         ms, n = eng.profile_get(cls)
         if n:
             classes[cls] = {"launches": int(n), "est_total_ms": round(ms, 2)}
 
+    # per-node Krylov iterations of the last step, summed over its refinement loops (this rank's nodes)
+    node_its = {}
+    for per_loop in res.stats.get("node_iterations", []):
+        for g, v in zip(res.stats.get("local_nodes", []), per_loop):
+            node_its[int(g)] = node_its.get(int(g), 0) + int(v)
+    nr, rk, transport = eng.comm_size, eng.comm_rank, {0: "none", 1: "rccl", 2: "shm (ranks share a device)"}
+    tr = eng.comm_transport() if hasattr(eng, "comm_transport") else 0
+    contour_txt = "%s quadrature, ellipse ratio fpm[18]=%d (a/b = %.2f)" % (args.contour, args.aspect, args.aspect / 100.0)
+
     out = {
         "metric": "eigenpairs/sec + max residual, 16-node contour", "value": round(value, 3), "unit": "eigenpairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 2),
+        "n_gpus": nr, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg3: N=50000 sparse symmetric generalized (3-D Laplacian 50x40x25, B=I+0.1A), "
-                               "interval (0,0.1775), 16 Gauss nodes, M0=64, tol 1e-12",
+                               "interval (0,0.1775), 16 nodes (%s), M0=64, tol 1e-12" % contour_txt,
                    "solver": "batched %s, fp64, warm-started from Ritz pairs, inner rtol %g, <=%d its/loop"
                              % ("COCG (BiCG for the complex-symmetric shifted systems)" if args.solver == "cocg" else "BiCGStab",
                                 args.inner_rtol, args.maxit),
-                   "parallelism": "%d ranks = (node groups) x (column groups of >=16 RHS columns), near/far-axis nodes paired, 1 all-reduce of Q_proj per loop" % world},
+                   "parallelism": "%d ranks = (node groups) x (column groups of >=16 RHS columns), near/far-axis nodes paired, "
+                                  "1 packed all-reduce of Q_proj per loop inside the C ABI (transport: %s)" % (nr, transport.get(tr, "?"))},
         "eigenpairs": int(res.M), "expected_eigenpairs": int(len(inside)), "max_residual": max_res,
         "max_eigenvalue_error": eig_err, "loops": int(res.loop), "converged": bool(ok),
         "krylov_iterations_per_step": int(res.stats.get("krylov_iterations", 0)),
+        "node_iterations_last_step": {str(k): node_its[k] for k in sorted(node_its)},
         "phase_seconds_last_step": {k: round(v, 4) for k, v in res.stats.get("phase_seconds", {}).items()},
         "solve_seconds_last_step": round(float(res.stats.get("solve_seconds", 0.0)), 4),
-        "roofline": roofline, "roofline_other": roofline_other, "kernel_classes": classes,
-        "mixed_precision": {"value": round(mixed.M / mixed_elapsed, 3) if mixed.info == 0 else 0.0, "unit": "eigenpairs/s",
-                            "note": "same solve with complex64 Krylov correction panels (not the headline value)",
-                            "max_residual_device": float(mixed.epsout), "loops": int(mixed.loop)},
+        "roofline": cands[0] if cands else None, "roofline_other": cands[1:], "kernel_classes": classes,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(A, B, len(inside))
+    if rk == 0 and nr == 1:
+        # secondary measurements, none of them the headline value
+        fence()
+        step(32)
+        fence()
+        t1 = time.perf_counter()
+        mixed = step(32)
+        fence()
+        dtm = time.perf_counter() - t1
+        out["mixed_precision"] = {"value": round(mixed.M / dtm, 3) if mixed.info == 0 else 0.0, "unit": "eigenpairs/s",
+                                  "note": "same solve with complex64 Krylov correction panels (not the headline value)",
+                                  "max_residual_device": float(mixed.epsout), "loops": int(mixed.loop)}
+        if not args.no_default_contour:
+            step(64, 100, 0, 100)
+            fence()
+            t1 = time.perf_counter()
+            dflt = step(64, 100, 0, 100)
+            fence()
+            dtd = time.perf_counter() - t1
+            out["reference_default_contour"] = {
+                "value": round(dflt.M / dtd, 3) if dflt.info == 0 and dflt.M == len(inside) else 0.0, "unit": "eigenpairs/s",
+                "ms_per_step": round(1e3 * dtd, 2), "loops": int(dflt.loop), "krylov_iterations": int(dflt.stats.get("krylov_iterations", 0)),
+                "note": "same solve on the reference's default contour (Gauss, circle fpm[18]=100, <=100 its/loop): round 1's configuration"}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(A, B, inside, res.lambda_)
+        if not args.no_dense:
+            try:
+                out.update(dense_configs(fk, eng))
+            except Exception as exc:          # the headline line must survive a failure of the extra measurements
+                out["dense_error"] = repr(exc)
     if world > 1:
+        import torch.distributed as dist
+        eng.barrier()
+        eng.comm_destroy()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

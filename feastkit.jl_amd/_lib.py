@@ -34,6 +34,12 @@ SYMBOLS = {
     "feasthip_last_error": (C.c_char_p, [_vp]),
     "feasthip_set_stream": (_i, [_vp, _vp]),
     "feasthip_synchronize": (_i, [_vp]),
+    "feasthip_comm_unique_id": (_i, [C.c_char_p]),
+    "feasthip_comm_init_rank": (_i, [_vp, _i, _i, C.c_char_p, _i]),
+    "feasthip_comm_destroy": (_i, [_vp]),
+    "feasthip_comm_info": (_i, [_vp, _pi, _pi, _pi]),
+    "feasthip_allreduce_sum_dev": (_i, [_vp, _vp, _i64]),
+    "feasthip_set_column_block": (_i, [_vp, _i64, _i64]),
     "feasthip_set_dense": (_i, [_vp, _i64, _i, _vp, _i64, _vp, _i64]),
     "feasthip_set_csr": (_i, [_vp, _i64, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "feasthip_set_contour": (_i, [_vp, _i, _vp, _vp, _d]),
@@ -60,7 +66,11 @@ SYMBOLS = {
     "feasthip_profile_enable": (_i, [_vp, _i]),
     "feasthip_profile_reset": (_i, [_vp]),
     "feasthip_profile_get": (_i, [_vp, C.c_char_p, _pd, _pi64]),
+    "feasthip_profile_set_period": (_i, [_vp, _i]),
+    "feasthip_profile_get_work": (_i, [_vp, C.c_char_p, _pd]),
 }
+
+UNIQUE_ID_BYTES = 128      # FEASTHIP_UNIQUE_ID_BYTES
 
 _lib = None
 

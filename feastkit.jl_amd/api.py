@@ -36,7 +36,16 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30):
     ldab = 2 * kl + ku + 1
     if 2 * kl + ku + 1 <= 3500 and ldab * A.shape[0] * 16 * max(nodes, 1) <= budget_bytes and kl + ku <= 512:
         return "banded"
-    return "bicgstab"
+    return "krylov"
+
+
+# What `solver=:direct` (the reference's default, UMFPACK for sparse input: src/sparse/feast_sparse.jl:334-342 via
+# src/core/feast_backend_utils.jl:166-198) maps to when the pattern is not a narrow band: the batched Krylov path in
+# the configuration that converges on large problems -- COCG for real-symmetric input (z B - A is complex symmetric:
+# one operator application per iteration), BiCGStab otherwise; Ritz-pair warm starts, inexact inner solves (relative
+# reduction 3e-2 per refinement loop, at most 100 iterations per loop) and, for real input, the real projection.
+# The outer stop test is the reference's (max residual of the pairs inside <= 10^-fpm[3]).
+_KRYLOV_DEFAULT = dict(warm_start=True, inner_rtol=3e-2, solver_maxiter=100)
 
 
 def _engine(engine, device):
@@ -44,7 +53,7 @@ def _engine(engine, device):
 
 
 def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="direct", solver_tol=0.0,
-          solver_maxiter=500, solver_restart=30, warm_start=False, inner_rtol=None, real_projection=None,
+          solver_maxiter=None, solver_restart=30, warm_start=None, inner_rtol=None, real_projection=None,
           inner_precision=64, group=None, engine=None, device=0, Q0=None):
     """feast(A, [B,] (Emin, Emax); M0, fpm, backend=:hip) for real-symmetric / Hermitian
     dense (numpy) or sparse (scipy) matrices.  Real input is complexified and the result is
@@ -73,6 +82,14 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         # the reference's sparse default is UMFPACK; the :hip backend has a direct path for band
         # matrices (batched banded LU) and otherwise the batched Krylov solver (north_star)
         solver = _sparse_direct_solver(A, B, int(fpm[2]))
+        if solver == "krylov":
+            solver = "cocg" if real_input else "bicgstab"
+            if warm_start is None and inner_rtol is None:
+                warm_start, inner_rtol = _KRYLOV_DEFAULT["warm_start"], _KRYLOV_DEFAULT["inner_rtol"]
+                if solver_maxiter is None:
+                    solver_maxiter = _KRYLOV_DEFAULT["solver_maxiter"]
+    warm_start = bool(warm_start)                 # an explicitly named iterative solver keeps the reference's zero guess
+    solver_maxiter = 500 if solver_maxiter is None else int(solver_maxiter)
     eng = _engine(engine, device)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,

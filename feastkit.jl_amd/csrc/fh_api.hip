@@ -5,6 +5,7 @@
 #include "fh_dense.hpp"
 #include "fh_banded.hpp"
 #include "fh_eig.hpp"
+#include "fh_comm.hpp"
 #include "../../include/feasthip.h"
 
 #include <algorithm>
@@ -61,7 +62,7 @@ void fh_prof_begin(feasthip_ctx* h, const char* cls) {
     if (!h->profiling) return;
     fh_prof_class& pc = h->prof[cls];
     pc.launches += 1;
-    const int period = fh_prof_period();
+    const int period = h->prof_period > 0 ? h->prof_period : fh_prof_period();
     static const bool nopool = getenv("FH_PROF_NOPOOL") != nullptr;
     const long eff = (long)period * h->prof_mult;
     if (eff > 1 && (pc.launches % eff) != 1) return;
@@ -109,7 +110,7 @@ void fh_prof_collect(feasthip_ctx* h) {
     // less often (91 stays coprime to the iteration caps), up to 1 launch in 637.
     h->prof_host_s += fh_now_s() - t_in;
     const double wall = fh_now_s() - h->prof_t0;
-    if (fh_prof_period() > 1 && wall > 0.05 && h->prof_host_s > 0.01 * wall && h->prof_mult < 49) {   // period 1 = exact timing requested
+    if ((h->prof_period > 0 ? h->prof_period : fh_prof_period()) > 1 && wall > 0.05 && h->prof_host_s > 0.01 * wall && h->prof_mult < 49) {   // period 1 = exact timing requested
         h->prof_mult *= 7;
         h->prof_host_s = 0.0;
         h->prof_t0 = fh_now_s();
@@ -177,6 +178,7 @@ extern "C" int feasthip_destroy(feasthip_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    fh_comm_destroy(h);
     fh_prof_collect(h);
     fh_free_problem(h);
     fh_free_bufs(h);
@@ -591,7 +593,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     fh_fin_args fa;
     fa.s = s; fa.partial1 = part1; fa.partial2 = part2; fa.m = m; fa.rtol = h->rtol; fa.atol = h->atol;
     fa.atol_scale = nullptr; fa.mode = method; fa.col_mask = nullptr;
-    if (!h->col_mask.empty()) {
+    if (h->mask_live && !h->col_mask.empty()) {
         std::vector<int> mk(ld, 1);
         for (int c = 0; c < ld && c < (int)h->col_mask.size(); ++c) mk[c] = h->col_mask[c];
         if ((rc = fh_get_buf(h, "kry_colmask", ld * sizeof(int), &p))) return rc;
@@ -753,7 +755,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
             int i = e * ld + c;
             mx = std::max(mx, iters[i]);
             res.col_iters.push_back(iters[i]);
-            if (active[i]) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
+            if (active[i] || !std::isfinite(rnorm[i])) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
             else if (status[i] == 8 && !(rnorm[i] <= h->atol + h->rtol * r0[i])) st = std::max(st, (int)FEASTHIP_ERROR_NO_CONVERGENCE);
             if (r0[i] > 0) res.max_rel_res = std::max(res.max_rel_res, rnorm[i] / r0[i]);
         }
@@ -1047,8 +1049,10 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     std::vector<int> status(nodes, 0);
     cplx* sum_acc = nullptr;
 
-    hipEvent_t ev0, ev1;
-    FH_CHECK(hipEventCreate(&ev0)); FH_CHECK(hipEventCreate(&ev1));
+    // destroyed on every return path (the solver branches below return early on errors)
+    struct ev_guard { hipEvent_t a = nullptr, b = nullptr; ~ev_guard() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } } evg;
+    FH_CHECK(hipEventCreate(&evg.a)); FH_CHECK(hipEventCreate(&evg.b));
+    const hipEvent_t ev0 = evg.a, ev1 = evg.b;
     FH_CHECK(hipEventRecord(ev0, h->stream));
     if (h->solver == FEASTHIP_SOLVER_LU) {
         if (h->kind != 1) { h->last_error = "solver LU requires a dense matrix (sparse direct factorisation is not provided; use BICGSTAB)"; return FEASTHIP_ERROR_FPM; }
@@ -1174,7 +1178,6 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         stats->seconds_solve = ms * 1e-3;
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
-    hipEventDestroy(ev0); hipEventDestroy(ev1);
     fh_prof_collect(h);
     FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
     return 0;
@@ -1182,8 +1185,8 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
 
 // m > 64: the columns of Q are independent right-hand sides, so the sweep runs panel by panel
 // (64 columns each); LU factors are shared by the panels through the per-node cache.
-static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
-                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+static int fh_contour_apply_local(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
+                                  cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
     if (m64 <= FH_MAX_LD) return fh_contour_apply_panel(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
     int rc = fh_check_problem(h, m64, 1);
     if (rc) return rc;
@@ -1220,11 +1223,108 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     return 0;
 }
 
+// The sweep as the caller sees it: this rank's nodes x this rank's column block (feasthip_set_column_block),
+// then -- when a communicator is attached -- ONE packed all-reduce
+//     [ Q_proj (N*m reals for a real-projection sweep, else 2*N*m) | zAq | zSq | per-node failure flags ]
+// on the handle's stream: the image of MPI.Allreduce in src/parallel/feast_mpi.jl:117-119, 856-858 and of the
+// master sum src/parallel/feast_parallel.jl:497-503.  With a communicator node_status is GLOBAL (ne entries,
+// indexed by contour node), without one it is per local node as before.
+static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
+                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+    const int nr = fh_comm_nranks(h);
+    int64_t c0 = 0, c1 = m64;
+    if (h->col_block_hi >= 0) { c0 = std::min(h->col_block_lo, m64); c1 = std::min(std::max(h->col_block_hi, c0), m64); }
+    const bool full = (c0 == 0 && c1 == m64);
+    if (nr == 1 && full) return fh_contour_apply_local(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
+    int rc = fh_check_problem(h, m64, 1);
+    if (rc) return rc;
+    if (!full && (dzAq || dzSq)) { h->last_error = "contour_apply: moment matrices need the full column block"; return FEASTHIP_ERROR_M0; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int N = (int)fh_N(h), m = (int)m64, nodes = h->node_count, ne = (int)h->zne.size();
+    std::vector<int> ns(std::max(nodes, 1), 0);
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!full) FH_CHECK(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream));
+    if (c1 > c0) {
+        const std::vector<int> mask = h->col_mask;
+        if (!mask.empty()) {
+            h->col_mask.clear();
+            for (int64_t c = c0; c < c1; ++c) h->col_mask.push_back(c < (int64_t)mask.size() ? mask[c] : 1);
+        }
+        rc = fh_contour_apply_local(h, c1 - c0, dQ + (size_t)c0 * N, ritz_lambda ? ritz_lambda + c0 : nullptr,
+                                    dQproj + (size_t)c0 * N, dzAq, dzSq, ns.data(), stats);
+        h->col_mask = mask;
+    } else {
+        FH_CHECK(hipStreamSynchronize(h->stream));
+    }
+    if (nr == 1) {
+        if (rc) return rc;
+        if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = ns[e];
+        return 0;
+    }
+    // a rank whose sweep failed still takes part in the reduce (its peers are waiting in it) and reports through
+    // the flags: every rank then sees the failure instead of blocking
+    const int local_rc = rc;
+    const size_t nq = (size_t)N * m * (h->real_projection ? 1 : 2);
+    const size_t nm = (size_t)m * m * 2;
+    const size_t total = nq + (dzAq ? nm : 0) + (dzSq ? nm : 0) + 2 * (size_t)ne + 1;
+    void* p;
+    if ((rc = fh_get_buf(h, "comm_pack", total * sizeof(double), &p))) return rc;
+    double* pack = (double*)p;
+    if (h->real_projection) fh_launch_pack_real(dQproj, pack, nq, h->stream);
+    else FH_CHECK(hipMemcpyAsync(pack, dQproj, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    size_t off = nq;
+    if (dzAq) { FH_CHECK(hipMemcpyAsync(pack + off, dzAq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
+    if (dzSq) { FH_CHECK(hipMemcpyAsync(pack + off, dzSq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
+    std::vector<double> flags(2 * (size_t)ne + 1, 0.0);
+    for (int e = 0; e < nodes; ++e) {
+        const int g = h->node_ids[e];
+        if (ns[e] == FEASTHIP_ERROR_LAPACK) flags[ne + g] = 1.0;
+        else if (ns[e] != 0) flags[g] = 1.0;
+    }
+    flags[2 * (size_t)ne] = local_rc ? 1.0 : 0.0;
+    FH_CHECK(hipMemcpyAsync(pack + off, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (local_rc) {
+        // our own payload may be garbage: contribute zeros so that the peers' sums stay finite
+        FH_CHECK(hipMemsetAsync(pack, 0, off * sizeof(double), h->stream));
+    }
+    fh_prof_begin(h, "allreduce");
+    rc = fh_comm_allreduce_sum(h, pack, total);
+    fh_prof_end(h);
+    if (rc) return rc;
+    if (h->real_projection) fh_launch_unpack_real(pack, dQproj, nq, h->stream);
+    else FH_CHECK(hipMemcpyAsync(dQproj, pack, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    off = nq;
+    if (dzAq) { FH_CHECK(hipMemcpyAsync(dzAq, pack + off, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
+    if (dzSq) { FH_CHECK(hipMemcpyAsync(dzSq, pack + off, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
+    FH_CHECK(hipMemcpyAsync(flags.data(), pack + off, flags.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (node_status)
+        for (int g = 0; g < ne; ++g)
+            node_status[g] = flags[ne + g] > 0.0 ? (int)FEASTHIP_ERROR_LAPACK : (flags[g] > 0.0 ? (int)FEASTHIP_ERROR_NO_CONVERGENCE : 0);
+    if (local_rc) return local_rc;
+    if (flags[2 * (size_t)ne] > 0.0) { h->last_error = "contour_apply: the sweep failed on another rank"; return FEASTHIP_ERROR_INTERNAL; }
+    return 0;
+}
+
+extern "C" int feasthip_set_column_block(feasthip_handle h, int64_t first, int64_t count) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (count < 0) { h->col_block_lo = 0; h->col_block_hi = -1; return 0; }
+    if (first < 0) { h->last_error = "set_column_block: first must be >= 0"; return FEASTHIP_ERROR_M0; }
+    h->col_block_lo = first; h->col_block_hi = first + count;
+    return 0;
+}
+
 extern "C" int feasthip_contour_apply_dev(feasthip_handle h, int64_t m, const void* dQ, const double* ritz_lambda_host,
                                           void* dQproj, void* dzAq, void* dzSq, int* node_status, feasthip_stats* stats) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     if (!dQ || !dQproj) { h->last_error = "contour_apply: null Q/Qproj"; return FEASTHIP_ERROR_INTERNAL; }
-    return fh_contour_apply_impl(h, m, (const cplx*)dQ, ritz_lambda_host, (cplx*)dQproj, (cplx*)dzAq, (cplx*)dzSq, node_status, stats);
+    // the column mask is one-shot: it applies to this sweep only and never leaks into later calls
+    // (shifted_solve / RCI jobs on the same handle), whatever the outcome of the sweep
+    h->mask_live = 1;
+    const int rc = fh_contour_apply_impl(h, m, (const cplx*)dQ, ritz_lambda_host, (cplx*)dQproj, (cplx*)dzAq, (cplx*)dzSq, node_status, stats);
+    h->mask_live = 0;
+    h->col_mask.clear();
+    return rc;
 }
 
 // host-pointer wrapper helpers
@@ -1247,7 +1347,10 @@ extern "C" int feasthip_contour_apply(feasthip_handle h, int64_t m, const void* 
     if ((rc = fh_get_buf(h, "host_Qproj", nb, &dP))) return rc;
     if (zAq && (rc = fh_get_buf(h, "host_zAq", mb, &dA))) return rc;
     if (zSq && (rc = fh_get_buf(h, "host_zSq", mb, &dS))) return rc;
+    h->mask_live = 1;
     rc = fh_contour_apply_impl(h, m, (const cplx*)dQ, ritz_lambda, (cplx*)dP, (cplx*)dA, (cplx*)dS, node_status, stats);
+    h->mask_live = 0;
+    h->col_mask.clear();
     if (rc) return rc;
     FH_CHECK(hipMemcpy(Qproj, dP, nb, hipMemcpyDeviceToHost));
     if (zAq) FH_CHECK(hipMemcpy(zAq, dA, mb, hipMemcpyDeviceToHost));
@@ -2121,7 +2224,20 @@ extern "C" int feasthip_profile_reset(feasthip_handle h) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     fh_prof_collect(h);
     h->prof.clear();
+    h->prof_work.clear();
+    h->prof_mult = 1;
     hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long));
+    return 0;
+}
+extern "C" int feasthip_profile_set_period(feasthip_handle h, int period) {
+    if (!h || period < 0) return FEASTHIP_ERROR_INTERNAL;
+    h->prof_period = period;
+    return 0;
+}
+extern "C" int feasthip_profile_get_work(feasthip_handle h, const char* kernel_class, double* work) {
+    if (!h || !kernel_class || !work) return FEASTHIP_ERROR_INTERNAL;
+    auto it = h->prof_work.find(kernel_class);
+    *work = it == h->prof_work.end() ? 0.0 : it->second;
     return 0;
 }
 extern "C" int feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms, int64_t* launches) {

@@ -112,8 +112,12 @@ struct fh_krylov_scalars {
     int* node_accum = nullptr;   // [nodes]: any column of the node did
 };
 
+struct fh_comm;   // fh_comm.hip: RCCL (or shared-device) communicator attached by feasthip_comm_init_rank
+
 struct feasthip_ctx {
     int device = 0;
+    fh_comm* comm = nullptr;
+    int64_t col_block_lo = 0, col_block_hi = -1;   // feasthip_set_column_block: columns this rank sweeps (hi < 0: all)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -155,6 +159,7 @@ struct feasthip_ctx {
     std::vector<int> band_valid;
     std::vector<cplx> band_z;
     std::vector<int> col_mask;    // feasthip_set_column_mask: columns with 0 are not iterated by the Krylov solvers
+    int mask_live = 0;            // set only while a contour_apply call runs: the mask is one-shot and never reaches shifted_solve
     int sum_mode = 1;             // COCG contour_apply accumulates alpha*p into one shared panel (FH_NO_SUM_MODE=1 disables)
     int lu_outer_block = 0;       // FH_LU_KB: outer block column of the two-level LU (multiple of 32); 0 = by size (128, 256 from N = 6144)
     int lu_panel_legacy = 0;      // FH_LU_PANEL_LEGACY=1: per-column global-memory panel kernel
@@ -169,6 +174,8 @@ struct feasthip_ctx {
     unsigned long long* d_counters = nullptr;   // [0] spmm node-launches, [1] spmm column passes
     int profiling = 0;
     std::map<std::string, fh_prof_class> prof;
+    std::map<std::string, double> prof_work;    // algorithmic work (flops) issued per class while profiling (dense MFMA classes)
+    int prof_period = 0;                        // feasthip_profile_set_period: 0 = default sampling, 1 = every launch
     std::vector<fh_event_pair> pending_events;
     std::vector<hipEvent_t> event_pool;         // recycled profiling events
     int prof_mult = 1;                          // sampling period multiplier, raised when the host cost of sampling shows

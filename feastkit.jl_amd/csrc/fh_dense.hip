@@ -1310,6 +1310,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     auto gemm = [&](int k0, int kd, int r0, int r1, int c0, int c1, const char* cls) {
         if (r1 <= r0 || c1 <= c0) return;
         fh_prof_begin(h, cls);
+        if (h->profiling) h->prof_work[cls] += 8.0 * (double)(r1 - r0) * (double)(c1 - c0) * (double)kd * (double)nf;   // real flops of the complex product
         const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
         const int sw = std::min(8, TC);
         const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);

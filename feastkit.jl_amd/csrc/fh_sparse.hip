@@ -571,8 +571,9 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fin_rho(fh_fin_args a) {
             a.s.rnorm[i] = rn;
             a.s.iters[i] += 1;
             int act = 1;
-            if (!(rn > a.s.target[i])) { act = 0; a.s.status[i] = 0; }
-            else if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
+            // non-finite first: `!(NaN > target)` is true and would mark a NaN residual as converged
+            if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
+            else if (!(rn > a.s.target[i])) { act = 0; a.s.status[i] = 0; }
             else {
                 cplx beta = cdiv(rho_new, a.s.rho[i]);
                 bool bad = cabs2(a.s.rho[i]) == 0.0;

@@ -48,6 +48,7 @@ class HipEngine:
         self.N = 0
         self.b_identity = True
         self.last_stats = {}
+        self.comm_size, self.comm_rank = 1, 0
 
     # -- lifecycle ----------------------------------------------------------------
     def close(self):
@@ -66,6 +67,77 @@ class HipEngine:
             msg = self.lib.feasthip_last_error(self.h)
             raise FeastHipError(rc, msg.decode() if msg else "")
         return rc
+
+    # -- communicator (the collective lives in the C ABI; the host only ships the unique id) -----
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        self._chk(self.lib.feasthip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks, rank, uid, transport="auto"):
+        """Attach rank ``rank`` of ``nranks`` to this handle (collective).  transport: "rccl" (one rank per
+        GPU, RCCL over xGMI), "shm" (ranks sharing one device: test rigs), "auto"."""
+        code = {"auto": 0, "rccl": 1, "shm": 2}[transport]
+        self._chk(self.lib.feasthip_comm_init_rank(self.h, int(nranks), int(rank), bytes(uid), code))
+        self.comm_size, self.comm_rank = int(nranks), int(rank)
+
+    def comm_init_from_group(self, group=None, transport="auto"):
+        """Convenience for hosts that already run a ``torch.distributed`` group (any backend; it is used as the
+        CONTROL plane only): rank 0's unique id is broadcast through it, and ranks that share a HIP device are
+        detected so that "auto" picks the shared-device transport for them.  The data plane -- the per-loop sum of
+        Q_proj -- is the library's own RCCL all-reduce."""
+        import socket
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if world == 1:
+            return
+        box = [self.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        props = self.torch.cuda.get_device_properties(self.device)
+        ident = (socket.gethostname(), str(getattr(props, "uuid", "")), int(getattr(props, "pci_domain_id", 0)),
+                 int(getattr(props, "pci_bus_id", self.device.index)), int(getattr(props, "pci_device_id", 0)))
+        idents = [None] * world
+        dist.all_gather_object(idents, ident, group=group)
+        if transport == "auto":
+            transport = "shm" if len(set(idents)) < world else "rccl"
+        self.comm_init(world, rank, box[0], transport)
+
+    def comm_transport(self):
+        """0 none, 1 RCCL, 2 shared-device (shm)."""
+        n, r, t = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.feasthip_comm_info(self.h, C.byref(n), C.byref(r), C.byref(t)))
+        return int(t.value)
+
+    def comm_destroy(self):
+        self._chk(self.lib.feasthip_comm_destroy(self.h))
+        self.comm_size, self.comm_rank = 1, 0
+
+    def set_column_block(self, first=0, count=-1):
+        """Columns [first, first+count) of the following contour_apply calls are swept by this rank (count < 0:
+        all); the rest arrives through the all-reduce."""
+        self._chk(self.lib.feasthip_set_column_block(self.h, int(first), int(count)))
+
+    def allreduce_sum_(self, t):
+        """In-place sum over the communicator of a contiguous float64/complex128 device tensor (library RCCL)."""
+        if self.comm_size == 1:
+            return t
+        assert t.is_contiguous() and t.device == self.device
+        n = t.numel() * (2 if t.is_complex() else 1)
+        self._sync_stream()
+        self._chk(self.lib.feasthip_allreduce_sum_dev(self.h, C.c_void_p(t.data_ptr()), n))
+        return t
+
+    def barrier(self):
+        one = self.torch.ones(1, dtype=self.torch.float64, device=self.device)
+        self.allreduce_sum_(one)
+
+    def max_over_ranks(self, value):
+        """max of a host scalar over the ranks (sum of a one-hot vector through the library's all-reduce)."""
+        if self.comm_size == 1:
+            return float(value)
+        v = self.torch.zeros(self.comm_size, dtype=self.torch.float64, device=self.device)
+        v[self.comm_rank] = float(value)
+        return float(self.allreduce_sum_(v).max().item())
 
     # -- problem ------------------------------------------------------------------
     def set_problem(self, A, B=None):
@@ -175,15 +247,6 @@ class HipEngine:
             a = a[:m]
         return np.asfortranarray(a.T)
 
-    def allreduce_sum(self, dX, group=None):
-        """RCCL all-reduce over xGMI of a complex block (as 2*count f64), the image of
-        MPI.Allreduce in src/parallel/feast_mpi.jl:117-119, 856-858."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.torch.view_as_real(dX), op=dist.ReduceOp.SUM, group=group)
-            self.torch.cuda.current_stream(self.device).synchronize()   # result visible to the library's stream
-        return dX
-
     def _sync_stream(self):
         """Order the library behind torch.  torch's default stream has handle 0, for which
         the library falls back to its own non-blocking stream, so pending torch work (slice
@@ -195,7 +258,9 @@ class HipEngine:
 
     # -- hot path -------------------------------------------------------------------
     def contour_apply(self, dQ, m, ritz_lambda=None, want_moments=False):
-        """Q_proj (this rank's partial sum), per-node status, stats  [+ zAq, zSq]."""
+        """Q_proj, per-node status, stats  [+ zAq, zSq].  With a communicator attached everything returned is
+        already summed over the ranks (one packed RCCL all-reduce inside the call) and ``status`` is indexed by
+        contour node; without one it is this handle's partial sum and ``status`` is per local node."""
         self._sync_stream()
         dP = self.empty(dQ.shape[0])
         status = np.zeros(max(1, self.ne), dtype=np.int32)
@@ -286,6 +351,14 @@ class HipEngine:
     # -- measurement ----------------------------------------------------------------
     def profile_enable(self, on=True):
         self._chk(self.lib.feasthip_profile_enable(self.h, int(on)))
+
+    def profile_set_period(self, period):
+        self._chk(self.lib.feasthip_profile_set_period(self.h, int(period)))
+
+    def profile_get_work(self, cls):
+        w = C.c_double(0)
+        self._chk(self.lib.feasthip_profile_get_work(self.h, cls.encode(), C.byref(w)))
+        return w.value
 
     def profile_reset(self):
         self._chk(self.lib.feasthip_profile_reset(self.h))

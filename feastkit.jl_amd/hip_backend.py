@@ -10,11 +10,14 @@ per-quadrature-node operation.
   feast_hip_complex_symmetric -- complex-symmetric sibling of variant A (q^T instead of q^H)
         src/dense/feast_dense.jl:1026-1259, src/sparse/feast_sparse.jl:509-711
 
-Quadrature nodes are block-partitioned over the ranks of a ``torch.distributed`` process
-group exactly like ``distribute_contour_points`` (src/parallel/feast_parallel.jl:433-447);
-each rank sweeps its nodes, Q_proj is summed with one all-reduce per refinement loop
-(RCCL over xGMI; the image of src/parallel/feast_mpi.jl:117-119) and every rank then runs
-the reduced eigenproblem redundantly, as the MPI path does (src/parallel/feast_mpi.jl:121-139).
+Quadrature nodes are block-partitioned over the ranks of the communicator attached to the engine
+(``feasthip_comm_init_rank``) exactly like ``distribute_contour_points``
+(src/parallel/feast_parallel.jl:433-447); each rank sweeps its nodes and the C ABI itself sums
+Q_proj (and the per-node status) with ONE packed RCCL all-reduce over xGMI inside every
+``contour_apply`` call -- the image of src/parallel/feast_mpi.jl:117-119 -- after which every rank
+runs the reduced eigenproblem redundantly, as the MPI path does (src/parallel/feast_mpi.jl:121-139).
+No ``torch.distributed`` collective is issued by this module; a ``group`` argument is only a
+convenience to attach the engine's communicator through an existing process group.
 
 The reduced M0 x M0 eigenproblem stays on host LAPACK.
 """
@@ -70,12 +73,18 @@ def seeded_subspace(N, M0, seed=20260515, complex_values=False):
     return np.asfortranarray(Q / nrm)
 
 
-def _world(group):
+def _world(engine, group=None):
+    """(rank, world) of the communicator attached to ``engine``.  When none is attached but the host runs a
+    ``torch.distributed`` group of more than one rank, the engine is attached through it first (control plane
+    only: the unique id travels over the group, the reductions are the library's own)."""
+    if getattr(engine, "comm_size", 1) > 1:
+        return engine.comm_rank, engine.comm_size
     try:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(group), dist.get_world_size(group)
-    except Exception:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            engine.comm_init_from_group(group)
+            return engine.comm_rank, engine.comm_size
+    except ImportError:
         pass
     return 0, 1
 
@@ -138,7 +147,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     info = check_feast_srci_input(N, M0, Emin, Emax)
     if info:
         return FeastResult(np.zeros(0), np.zeros((N, 0), dtype=np.complex128), 0, np.zeros(0), info, math.inf, 0)
-    rank, world = _world(group)
+    rank, world = _world(engine, group)
     iterative = solver not in ("direct", "lu", "banded")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
 
@@ -173,9 +182,11 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         nodes_here = balanced_contour_points(len(Zne), node_groups)[node_rank]
         engine.set_node_list(nodes_here)
         count = len(nodes_here)
+        local_nodes = list(nodes_here)
     else:
         first, count = distribute_contour_points(len(Zne), node_groups)[node_rank]
         engine.set_node_range(first, count)
+        local_nodes = list(range(first, first + count))
 
     def column_block(ncols):
         """[c0, c1) of this rank's column group: blocks in multiples of 16, remainder to the last."""
@@ -220,7 +231,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     eps_hist, inner_cap = [], int(solver_maxiter)
     dX = None
     stats = {"setup_seconds": t_setup, "krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0,
-             "solve_seconds": 0.0, "loops": [], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
+             "solve_seconds": 0.0, "loops": [], "node_iterations": [], "local_nodes": [int(v) for v in local_nodes], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
                                                                    "project": 0.0, "eig": 0.0, "ritz": 0.0}}
     ph = stats["phase_seconds"]
     tick = time.perf_counter
@@ -235,32 +246,23 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
             # stay in the subspace, scaled by the filter value, but no solves are spent on them
             col_mask = np.array([1 if Emin <= lam_guess[c] <= Emax else 0 for c in range(active)], dtype=np.int32)
         if hasattr(engine, "set_column_mask"):
-            engine.set_column_mask(col_mask if column_groups == 1 else None)
-        if column_groups == 1:
-            dP, status, st = engine.contour_apply(dQ, active, lam_guess)
-        else:
+            engine.set_column_mask(col_mask)                    # one-shot: consumed by the sweep below
+        if column_groups > 1:
             c0, c1 = column_block(active)
-            dP = engine.empty(dQ.shape[0])
-            dP.zero_()
-            status, st = np.zeros(max(1, count), dtype=np.int32), {}
-            if c1 > c0:
-                if hasattr(engine, "set_column_mask"):
-                    engine.set_column_mask(None if col_mask is None else col_mask[c0:c1])
-                dPs, status, st = engine.contour_apply(dQ[c0:c1], c1 - c0, None if lam_guess is None else lam_guess[c0:c1])
-                dP[c0:c1] = dPs[:c1 - c0]
+            engine.set_column_block(c0, c1 - c0)
+        # one call = this rank's (nodes x column block) sweep + the packed all-reduce inside the C ABI:
+        # dP and status come back summed over all ranks (status indexed by contour node when world > 1)
+        dP, status, st = engine.contour_apply(dQ, active, lam_guess)
+        if column_groups > 1:
+            engine.set_column_block(0, -1)
         ph["apply"] += tick() - t_
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
         stats["spmm_calls"] += st.get("spmm_calls", 0)
         stats["factorizations"] += st.get("factorizations", 0)
         stats["solve_seconds"] += st.get("seconds_solve", 0.0)
-        local_fail = int(np.max(status[:max(count, 1)])) if count > 0 else 0
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            flag = torch.tensor([float(local_fail)], dtype=torch.float64, device=dP.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            local_fail = int(flag.item())
-            engine.allreduce_sum(dP, group)
+        if hasattr(engine, "last_node_iterations"):
+            stats["node_iterations"].append([int(v) for v in engine.last_node_iterations(count)])
+        local_fail = int(np.max(status)) if (world > 1 or count > 0) else 0
         if local_fail == 8 or (local_fail == 5 and not warm_start):
             # direct: singular shift -> info 8 (src/dense/feast_dense.jl:199-203);
             # reference GMRES failure -> info 5 (src/dense/feast_dense.jl:221-225)
@@ -396,7 +398,7 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
         return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 2, math.inf, 0)
     if not r > 0:
         return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0), 4, math.inf, 0)
-    rank, world = _world(group)
+    rank, world = _world(engine, group)
     iterative = solver not in ("direct", "lu", "banded")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
     Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
@@ -428,14 +430,7 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
         stats["factorizations"] += st.get("factorizations", 0)
         stats["solve_seconds"] += st.get("seconds_solve", 0.0)
-        fail = int(np.max(status[:max(count, 1)])) if count > 0 else 0
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            flag = torch.tensor([float(fail)], dtype=torch.float64, device=dq.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            fail = int(flag.item())
-            engine.allreduce_sum(dq, group)
+        fail = int(np.max(status)) if (world > 1 or count > 0) else 0     # summed over the ranks inside the call
         if fail:
             return FeastResult(np.zeros(0, complex), np.zeros((N, 0), complex), 0, np.zeros(0),
                                int(FeastError.Feast_ERROR_LAPACK if fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE),
@@ -494,7 +489,7 @@ def feast_hip_complex_symmetric(engine, A, B, Emid, r, M0, fpm, *, solver="direc
         sym = (abs(Mx - Mx.T).max() == 0) if _sp.issparse(Mx) else np.array_equal(Mx, Mx.T)
         if not sym:                                          # check_complex_symmetric, feast_dense.jl:1038
             raise ValueError(f"Matrix {name} must be complex symmetric ({name} == transpose({name}))")
-    rank_, world = _world(group)
+    rank_, world = _world(engine, group)
     iterative = solver not in ("direct", "lu", "banded")
     tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
     Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
@@ -521,14 +516,7 @@ def feast_hip_complex_symmetric(engine, A, B, Emid, r, M0, fpm, *, solver="direc
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
         stats["factorizations"] += st.get("factorizations", 0)
         stats["solve_seconds"] += st.get("seconds_solve", 0.0)
-        fail = int(np.max(status[:max(count, 1)])) if count > 0 else 0
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            flag = torch.tensor([float(fail)], dtype=torch.float64, device=dP.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            fail = int(flag.item())
-            engine.allreduce_sum(dP, group)
+        fail = int(np.max(status)) if (world > 1 or count > 0) else 0
         if fail:
             info = int(FeastError.Feast_ERROR_LAPACK if fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE)
             break
@@ -592,7 +580,7 @@ def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None
     info = check_feast_srci_input(N, M0, Emin, Emax)
     if info:
         return FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), info, math.inf, 0)
-    rank, world = _world(group)
+    rank, world = _world(engine, group)
     Bm = B if B is not None else (_sp.identity(N, format="csr") if _sp.issparse(A) else np.eye(N))
     engine.set_problem(A, Bm)
     Zne, Wne = feast_contour(Emin, Emax, fpm)
@@ -609,14 +597,8 @@ def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None
     q = np.zeros((N, M0))
     for loop in range(1, max_loops + 1):
         dQ = engine.upload(work.astype(np.complex128))
+        # Q_proj and both moment matrices come back summed over the ranks (feast_mpi.jl:117-119)
         dP, status, st, Aq, Sq = engine.contour_apply(dQ, M0, None, want_moments=True)
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            engine.allreduce_sum(dP, group)
-            red = torch.tensor(np.stack([Aq.real, Sq.real]), dtype=torch.float64, device=dP.device)
-            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)      # feast_mpi.jl:117-119
-            Aq, Sq = red[0].cpu().numpy(), red[1].cpu().numpy()
         Aq, Sq = np.real(Aq), np.real(Sq)
         Q_proj = np.real(engine.download(dP, M0))
         try:

@@ -90,6 +90,32 @@ const char* feasthip_last_error(feasthip_handle h);
 int  feasthip_set_stream(feasthip_handle h, void* hip_stream);
 int  feasthip_synchronize(feasthip_handle h);
 
+/* ---- multi-GPU: one handle per GPU, one process (or task) per handle ---------------------------- */
+/* The reference reduces inside its parallel backends: MPI.Allreduce(local_Aq/local_Sq/local_Q, +, comm)
+ * (src/parallel/feast_mpi.jl:117-119, 856-858, 1001) and the master sum over worker results
+ * (src/parallel/feast_parallel.jl:497-503).  Here the handle owns the collective: once a communicator is
+ * attached, feasthip_contour_apply[_dev] returns Qproj (and zAq/zSq, node_status) already summed over all
+ * ranks -- ONE packed RCCL all-reduce over xGMI per refinement loop, ordered on the handle's stream.
+ *
+ * feasthip_comm_unique_id: rank 0 calls it (ncclGetUniqueId) and ships the 128 bytes to the other ranks by
+ *   whatever the host has (MPI.bcast in a Julia host, a TCP store in Python).
+ * feasthip_comm_init_rank: collective; attaches rank `rank` of `nranks` to the handle's device.
+ *   transport FEASTHIP_COMM_RCCL: librccl (resolved at run time), one rank per GPU.
+ *   transport FEASTHIP_COMM_SHM : for ranks that SHARE a HIP device (RCCL refuses that); rendezvous through
+ *     POSIX shared memory, peers' staging buffers mapped with HIP IPC, summed in rank order by a kernel
+ *     (bitwise identical on every rank).  A rehearsal transport for one-GPU test rigs, host-synchronous.
+ *   transport FEASTHIP_COMM_AUTO: RCCL unless the environment says FEASTHIP_COMM_TRANSPORT=shm.
+ * feasthip_allreduce_sum_dev: in-place SUM of `count` doubles at device pointer dptr over the ranks (the
+ *   reduction contour_apply uses, exposed for the host's own small reductions, e.g. residual blocks
+ *   src/parallel/feast_mpi.jl:264-284).  Returns after the result is visible.                          */
+#define FEASTHIP_UNIQUE_ID_BYTES 128
+enum { FEASTHIP_COMM_AUTO = 0, FEASTHIP_COMM_RCCL = 1, FEASTHIP_COMM_SHM = 2 };
+int  feasthip_comm_unique_id(char* uid /* FEASTHIP_UNIQUE_ID_BYTES */);
+int  feasthip_comm_init_rank(feasthip_handle h, int nranks, int rank, const char* uid, int transport);
+int  feasthip_comm_destroy(feasthip_handle h);
+int  feasthip_comm_info(feasthip_handle h, int* nranks, int* rank, int* transport);
+int  feasthip_allreduce_sum_dev(feasthip_handle h, void* dptr, int64_t count);
+
 /* ---- problem definition ---------------------------------------------------------- */
 /* Dense A (and B, NULL => identity), column-major, lda/ldb >= N.
  * Replaces the Matrix arguments of feast_sygv!/feast_hegv!/feast_gegv!
@@ -132,11 +158,20 @@ int  feasthip_set_node_range(feasthip_handle h, int first, int count);
  * summed result is independent of the assignment.                                       */
 int  feasthip_set_node_list(feasthip_handle h, int count, const int* indices);
 
+/* Column block of this handle: the following contour_apply calls sweep only columns [first, first+count) of the
+ * m columns they are given (the rest of Qproj is zero on this rank and filled in by the all-reduce); count < 0
+ * restores "all columns".  The reference shards quadrature nodes only (src/parallel/feast_parallel.jl:433-447);
+ * with Krylov solves the iteration counts of the nodes differ by 10x while the columns of a node cost the same,
+ * so ranks are arranged as (node groups) x (column groups).                                                  */
+int  feasthip_set_column_block(feasthip_handle h, int64_t first, int64_t count);
+
 /* Inexact-FEAST extension (not in the reference): columns c < m with mask[c] == 0 keep their initial
  * guess (the Ritz warm start q_c/(z - lambda_c) when ritz_lambda is given) and are never iterated by
  * the Krylov solvers of the following contour_apply calls.  Used to stop spending solves on the
  * guard columns (Ritz values outside the interval) once the subspace has settled.  mask == NULL or
- * m == 0 clears it.  Ignored by the LU path.                                                */
+ * m == 0 clears it.  Ignored by the LU path.  The mask is ONE-SHOT: it is consumed by the next
+ * contour_apply call (cleared when that call returns, whatever its outcome) and never applies to
+ * feasthip_shifted_solve.                                                                    */
 int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
 
 /* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
@@ -163,7 +198,8 @@ int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, 
  *   else m doubles (real Ritz values paired with the columns of Q, as in
  *   Q_basis <- solutions of src/dense/feast_dense.jl:336-337): iterative solvers start
  *   from Y0[:,j] = Q[:,j]/(z_e - lambda_j).  Ignored by the LU solver.
- * node_status[e_local]: 0 ok, 5 not converged, 8 singular.
+ * node_status[e_local]: 0 ok, 5 not converged, 8 singular.  With a communicator attached node_status is
+ *   GLOBAL: ne entries indexed by contour node (every rank receives the same vector).
  * Replaces: loop bodies src/dense/feast_dense.jl:171-232, src/sparse/feast_sparse.jl:318-370,
  * workers pfeast_solve_sparse_single_point (src/parallel/feast_parallel.jl:717-751) and
  * mpi_compute_local_moments (src/parallel/feast_mpi.jl:206-253).                          */
@@ -239,6 +275,11 @@ int  feasthip_profile_enable(feasthip_handle h, int enable);
 int  feasthip_profile_reset(feasthip_handle h);
 int  feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms,
                           int64_t* launches);
+/* Sampling period of the event timing: 0 = default (1 launch in 13), 1 = every launch (classes with few, very
+ * different launches: the dense LU).  feasthip_profile_get_work: algorithmic flops issued by a dense MFMA class
+ * ("lu_gemm", "lu_gemm_in") since the last reset, for the MFMA roofline of bench.py.                        */
+int  feasthip_profile_set_period(feasthip_handle h, int period);
+int  feasthip_profile_get_work(feasthip_handle h, const char* kernel_class, double* work);
 
 #ifdef __cplusplus
 }

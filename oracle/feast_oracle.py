@@ -535,6 +535,16 @@ def complex_to_real_result(res: FeastResult) -> FeastResult:
 #   per-node worker: src/parallel/feast_parallel.jl:717-751 (sparse), :227-274 (dense)
 #   outer loop     : src/parallel/feast_parallel.jl:450-572
 # ---------------------------------------------------------------------------
+def node_moments(work, Y, weight, z):
+    """One quadrature node's contribution to the moment matrices (variant B):
+        m_e = work^H Y_e ;  zAq += weight * m_e ;  zSq += weight * z_e * m_e
+    src/kernel/feast_kernel.jl:146-153, 522-524 (RCI kernels), src/parallel/feast_mpi.jl:236-245, 564-567.
+    Pinned by the reference's literal (test/test_allocation_helpers.jl:219-265): Aq = Wne[1]*(work'*workc),
+    Bq = Zne[1]*Aq.  Returns (weight*m_e, weight*z*m_e)."""
+    temp = work.conj().T @ Y
+    return weight * temp, weight * z * temp
+
+
 def pfeast_single_point(A, B, work, z, w, M0):
     """Returns (Aq, Sq, Q_proj) contribution of one node -- real parts, weight 2w."""
     N = A.shape[0]
@@ -546,9 +556,9 @@ def pfeast_single_point(A, B, work, z, w, M0):
     else:
         S = z * B - A
         Y = sla.lu_solve(sla.lu_factor(S), (B @ W).astype(np.complex128))
-    temp = W.T @ Y
     weight = 2 * w
-    return np.real(weight * temp), np.real(weight * z * temp), np.real(weight * Y)
+    a, s_ = node_moments(W, Y, weight, z)          # W is real here: W^H = W^T (feast_parallel.jl:742-747)
+    return np.real(a), np.real(s_), np.real(weight * Y)
 
 
 def pfeast_moments(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, nworkers=1, seed=20260515, Q0=None):
@@ -831,9 +841,9 @@ def rci_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, Q0=None, seed=20
             Y = np.linalg.solve(Zne[e] * Bd - A, Bd @ Q)
             wt = 2 * Wne[e]
             Qp += wt * Y
-            temp = Q.conj().T @ Y
-            zA += wt * temp
-            zS += wt * Zne[e] * temp
+            a, s_ = node_moments(Q, Y, wt, Zne[e])
+            zA += a
+            zS += s_
         try:
             w, V = _ggev_scaled(zS, zA)
         except Exception:

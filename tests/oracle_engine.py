@@ -16,6 +16,21 @@ class OracleEngine:
         self.last_stats = {}
         self.real_projection = False
         self.calls = {"contour_apply": 0}
+        self.comm_size, self.comm_rank, self.group = 1, 0, None
+        self.col_block = (0, -1)
+        self.col_mask = None
+
+    # the product engine owns its collective (RCCL inside the C ABI); this stand-in sums over a gloo group
+    def comm_init_from_group(self, group=None, transport="auto"):
+        import torch.distributed as dist
+        self.group = group
+        self.comm_rank, self.comm_size = dist.get_rank(group), dist.get_world_size(group)
+
+    def set_column_block(self, first=0, count=-1):
+        self.col_block = (int(first), int(count))
+
+    def set_column_mask(self, mask):
+        self.col_mask = None       # direct solves: nothing to skip
 
     def set_problem(self, A, B=None):
         self.sparse = sp.issparse(A)
@@ -57,12 +72,6 @@ class OracleEngine:
             a = a[:m]
         return np.asfortranarray(a.T)
 
-    def allreduce_sum(self, dX, group=None):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(torch.view_as_real(dX), op=dist.ReduceOp.SUM, group=group)
-        return dX
-
     def _solve(self, e, rhs):
         z = self.Zne[e]
         if e not in self.factors:
@@ -77,24 +86,49 @@ class OracleEngine:
     def contour_apply(self, dQ, m, ritz_lambda=None, want_moments=False):
         self.calls["contour_apply"] += 1
         Q = self.download(dQ)[:, :m]
+        c0, cnt = self.col_block
+        c1 = m if cnt < 0 else min(m, c0 + cnt)
+        c0 = min(c0, m)
         rhs = Q if self.B is None else self.B @ Q
         P = np.zeros((self.N, m), dtype=np.complex128)
-        for e in getattr(self, 'node_list', range(self.first, self.first + self.count)):
-            P += self.scale * self.Wne[e] * self._solve(e, rhs)
+        nodes = getattr(self, 'node_list', range(self.first, self.first + self.count))
+        if c1 > c0:
+            for e in nodes:
+                P[:, c0:c1] += self.scale * self.Wne[e] * self._solve(e, rhs[:, c0:c1])
         if self.real_projection:
             P = P.real.astype(np.complex128)
         out = torch.zeros((dQ.shape[0], self.N), dtype=torch.complex128)
         out[:m] = torch.from_numpy(np.ascontiguousarray(P.T))
         status = np.zeros(max(1, self.ne), dtype=np.int32)
         self.last_stats = {"krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0, "seconds_solve": 0.0}
+        zA = zS = None
         if want_moments:
             zA = np.zeros((m, m), dtype=np.complex128); zS = np.zeros((m, m), dtype=np.complex128)
-            for e in getattr(self, 'node_list', range(self.first, self.first + self.count)):
+            for e in nodes:
                 G = Q.conj().T @ self._solve(e, rhs)
                 zA += self.scale * self.Wne[e] * G
                 zS += self.scale * self.Wne[e] * self.Zne[e] * G
             if self.real_projection:
                 zA, zS = zA.real.astype(np.complex128), zS.real.astype(np.complex128)
+        if self.comm_size > 1:
+            # the ONE packed reduce of the C ABI: [Q_proj | zAq | zSq | status flags]
+            import torch.distributed as dist
+            parts = [torch.view_as_real(out).reshape(-1)]
+            if want_moments:
+                parts += [torch.from_numpy(np.ascontiguousarray(zA)).view(torch.float64).reshape(-1),
+                          torch.from_numpy(np.ascontiguousarray(zS)).view(torch.float64).reshape(-1)]
+            parts.append(torch.from_numpy(status.astype(np.float64)))
+            pack = torch.cat(parts)
+            dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=self.group)
+            n0 = parts[0].numel()
+            out = torch.view_as_complex(pack[:n0].reshape(dQ.shape[0], self.N, 2).contiguous())
+            off = n0
+            if want_moments:
+                k = 2 * m * m
+                zA = pack[off:off + k].numpy().view(np.complex128).reshape(m, m).copy(); off += k
+                zS = pack[off:off + k].numpy().view(np.complex128).reshape(m, m).copy(); off += k
+            status = (pack[off:].numpy() > 0).astype(np.int32) * 5
+        if want_moments:
             return out, status, self.last_stats, zA, zS
         return out, status, self.last_stats
 

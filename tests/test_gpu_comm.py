@@ -1,0 +1,188 @@
+"""The collective inside the C ABI (include/feasthip.h: feasthip_comm_*): the image of MPI.Allreduce in
+src/parallel/feast_mpi.jl:117-119, 856-858 and of the master sum src/parallel/feast_parallel.jl:497-503.
+
+RCCL refuses two ranks of one communicator on the same HIP device, and the test box has one GPU: the RCCL
+transport is exercised with a single rank, the multi-rank logic (packed reduce inside contour_apply, global
+node status, column blocks, failure propagation) through the shared-device transport, driven from plain
+ctypes workers that exchange the unique id through a file -- no torch.distributed anywhere."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import feast_oracle as fo
+import feastkit_jl_amd as fk
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_single_rank(engine):
+    import torch
+    eng = fk.HipEngine(0)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(1, 0, uid, "rccl")
+    assert (eng.comm_size, eng.comm_rank, eng.comm_transport()) == (1, 0, 1)
+    x = torch.randn(50000, dtype=torch.float64, device="cuda")
+    ref = x.clone()
+    eng.allreduce_sum_(x)
+    assert torch.equal(x, ref)
+    # a sweep on a handle with a (one-rank) communicator equals the plain sweep bit for bit
+    A, B, _ = fo.cfg3_problem(10, 8, 6)
+    Q = fk.seeded_subspace(A.shape[0], 16)
+    outs = []
+    for e in (eng, engine):
+        e.set_problem(A, B)
+        Z, W = fk.feast_contour(0.0, 0.6, fk.feastdefault(fk.feastinit()))
+        e.set_contour(Z, W, 2.0)
+        e.set_real_projection(True)
+        e.set_node_range(0, len(Z))
+        e.set_solver("bicgstab", rtol=1e-12, atol=0.0, maxit=2000)
+        dP, status, _ = e.contour_apply(e.upload(Q), 16)
+        assert int(np.max(status)) == 0
+        outs.append(e.download(dP, 16))
+    assert np.array_equal(outs[0], outs[1])
+    eng.comm_destroy()
+    eng.close()
+
+
+WORKER = r'''
+import os, sys, time
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, torch
+import feast_oracle as fo, feastkit_jl_amd as fk
+rank, world, out = int(sys.argv[1]), int(sys.argv[2]), r"{out}"
+eng = fk.HipEngine(0)
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    uid = eng.comm_unique_id()
+    open(uidf + ".tmp", "wb").write(uid); os.rename(uidf + ".tmp", uidf)     # the host's own out-of-band channel
+else:
+    t0 = time.time()
+    while not os.path.exists(uidf):
+        time.sleep(0.01); assert time.time() - t0 < 60
+    uid = open(uidf, "rb").read()
+eng.comm_init(world, rank, uid, "shm")
+assert (eng.comm_size, eng.comm_rank, eng.comm_transport()) == (world, rank, 2)
+# plain reduce: values, growth of the staging buffer, rank-order determinism
+x = torch.full((1000003,), float(rank + 1), dtype=torch.float64, device="cuda")
+eng.allreduce_sum_(x)
+assert bool((x == world * (world + 1) / 2).all())
+g = torch.Generator(); g.manual_seed(100 + rank)
+y = torch.randn(3 * 1000003, generator=g, dtype=torch.float64).cuda()      # larger than the first staging buffer
+eng.allreduce_sum_(y)
+ref = sum(torch.randn(3 * 1000003, generator=torch.Generator().manual_seed(100 + r), dtype=torch.float64) for r in range(world))
+assert torch.allclose(y.cpu(), ref, rtol=0, atol=1e-12)
+np.save(os.path.join(out, "y%d.npy" % rank), y.cpu().numpy())
+zc = torch.full((4097,), complex(rank, -rank), dtype=torch.complex128, device="cuda")
+eng.allreduce_sum_(zc)
+assert bool((zc == complex(sum(range(world)), -sum(range(world)))).all())
+assert eng.max_over_ranks(10.0 + rank) == 10.0 + world - 1
+# the sweep: nodes split over the ranks, ONE packed reduce inside contour_apply, global status
+A, B, _ = fo.cfg3_problem(10, 8, 6)
+m = 24
+Q = fk.seeded_subspace(A.shape[0], m)
+Z, W = fk.feast_contour(0.0, 0.6, fk.feastdefault(fk.feastinit()))
+def sweep(e, first, count, block=None, moments=False):
+    e.set_problem(A, B); e.set_contour(Z, W, 2.0); e.set_real_projection(True)
+    e.set_node_range(first, count); e.set_solver("bicgstab", rtol=1e-12, atol=0.0, maxit=3000)
+    if block is not None: e.set_column_block(*block)
+    r = e.contour_apply(e.upload(Q), m, None, want_moments=moments)
+    e.set_column_block(0, -1)
+    return r
+first, count = fk.distribute_contour_points(len(Z), world)[rank]
+dP, status, st = sweep(eng, first, count)
+assert len(status) >= len(Z) and int(np.max(status)) == 0
+solo = fk.HipEngine(0)
+dR, sR, _ = sweep(solo, 0, len(Z))
+P, R = eng.download(dP, m), solo.download(dR, m)
+assert np.abs(P - R).max() <= 1e-11 * np.abs(R).max(), np.abs(P - R).max()
+np.save(os.path.join(out, "p%d.npy" % rank), P)
+# moments ride in the same reduce
+dP2, status2, st2, Aq, Sq = sweep(eng, first, count, moments=True)
+dR2, sR2, _, Aq0, Sq0 = sweep(solo, 0, len(Z), moments=True)
+assert np.abs(Aq - Aq0).max() <= 1e-11 * np.abs(Aq0).max() and np.abs(Sq - Sq0).max() <= 1e-11 * np.abs(Sq0).max()
+# column blocks: every rank sweeps ALL nodes for its own columns, the reduce fills in the rest
+per = m // world
+c0 = rank * per; cnt = (m - c0) if rank == world - 1 else per
+dP3, status3, _ = sweep(eng, 0, len(Z), block=(c0, cnt))
+# (narrower panels take a different reduction order inside the Krylov dots: the solves agree to rtol x cond, not bitwise)
+assert np.abs(eng.download(dP3, m) - R).max() <= 1e-8 * np.abs(R).max()
+solo.set_column_block(c0, cnt)
+dR3, _, _ = sweep(solo, 0, len(Z), block=(c0, cnt))
+assert np.array_equal(eng.download(dP3, m)[:, c0:c0 + cnt], solo.download(dR3, m)[:, c0:c0 + cnt])   # own block: bitwise the local sweep
+# a node that does not converge on ONE rank is seen by every rank (no MAX reduce, no hang)
+eng.set_problem(A, B); eng.set_contour(Z, W, 2.0); eng.set_node_range(first, count)
+eng.set_solver("bicgstab", rtol=1e-10, atol=0.0, maxit=(2 if rank == world - 1 else 3000))
+dP4, status4, _ = eng.contour_apply(eng.upload(Q), m)
+lastfirst, lastcount = fk.distribute_contour_points(len(Z), world)[world - 1]
+assert all(int(status4[e]) == 5 for e in range(lastfirst, lastfirst + lastcount)), status4
+assert all(int(status4[e]) == 0 for e in range(0, lastfirst)), status4
+eng.barrier()
+eng.comm_destroy(); eng.close(); solo.close()
+print("rank", rank, "ok")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shared_device_ranks_through_ctypes(engine, tmp_path, world):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FEASTHIP_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    ys = [np.load(tmp_path / f"y{r}.npy") for r in range(world)]
+    ps = [np.load(tmp_path / f"p{r}.npy") for r in range(world)]
+    assert all(np.array_equal(ys[0], y) for y in ys[1:])      # summed in rank order: bitwise identical on every rank
+    assert all(np.array_equal(ps[0], p) for p in ps[1:])
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("feasthip_")]      # rendezvous segment unlinked
+
+
+CFG3 = r'''
+import os, sys, time
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, torch
+import feastkit_jl_amd as fk
+rank, world, out = int(sys.argv[1]), int(sys.argv[2]), r"{out}"
+eng = fk.HipEngine(0)
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    open(uidf + ".tmp", "wb").write(eng.comm_unique_id()); os.rename(uidf + ".tmp", uidf)
+else:
+    t0 = time.time()
+    while not os.path.exists(uidf):
+        time.sleep(0.01); assert time.time() - t0 < 120
+eng.comm_init(world, rank, open(uidf, "rb").read(), "shm")
+A, B, lam = fk.workloads.laplacian_3d_pencil(50, 40, 25, 0.1)
+inside = lam[(lam >= 0.0) & (lam <= 0.1775)]
+eng.set_problem(A, B)
+fpm = fk.feastinit(); fpm[2], fpm[4], fpm[18] = 16, 40, {aspect}
+r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.1775, 64, fpm, solver="cocg", warm_start=True, inner_rtol=3e-2, solver_maxiter={cap},
+                           preloaded=True, node_assignment="balanced", column_groups="auto", real_projection=True)
+res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+np.save(os.path.join(out, "c%d.npy" % rank), np.array([r.info, r.M, r.loop, r.epsout, res.max()] + list(np.sort(r.lambda_))))
+assert r.info == 0 and r.M == len(inside) and np.abs(np.sort(r.lambda_) - inside).max() < 1e-10 and res.max() < 1e-10
+eng.barrier(); eng.comm_destroy(); eng.close()
+'''
+
+
+@pytest.mark.parametrize("world,aspect,cap", [(2, 4000, 50), (4, 4000, 50), (4, 100, 100)])
+def test_cfg3_full_size_ranks_on_one_card(tmp_path, world, aspect, cap):
+    """BASELINE cfg 4's sharding at FULL size (N = 50 000, 16 nodes, M0 = 64) with 2 and 4 ranks on the one card of the
+    test box, the bench's solver settings and layouts (2 -> 1x2, 4 -> 1x4 column groups): every rank returns all 44
+    eigenpairs, eigenvalues within 1e-10 of the closed form, host-recomputed residual below 1e-10."""
+    script = tmp_path / "cfg3.py"
+    script.write_text(CFG3.format(root=ROOT, out=str(tmp_path), aspect=aspect, cap=cap))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FEASTHIP_COMM_TIMEOUT_S="300")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(world)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = [np.load(tmp_path / f"c{r}.npy") for r in range(world)]
+    assert all(np.array_equal(res[0], x) for x in res[1:])
+    assert int(res[0][1]) == 44

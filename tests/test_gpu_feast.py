@@ -211,6 +211,45 @@ def test_cfg3_reduced_reference_mode_and_fast_mode(engine):
         assert res.max() <= 1e-10        # residual recomputed in fp64 on the host
 
 
+def _cfg3_check(r, A, B, inside):
+    assert r.info == 0 and r.M == 44 and r.epsout <= 1e-12
+    assert np.abs(np.sort(r.lambda_) - inside).max() <= 1e-10
+    res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert res.max() <= 1e-12 * 10       # residual recomputed in fp64 on the host
+
+
+def test_cfg3_reference_default_call_full_size(engine):
+    """The reference's call for the headline workload with NO keyword beyond the problem definition:
+    feast(A, B, (Emin, Emax); M0=64, fpm[2]=16).  The reference dispatches sparse input to its direct solver
+    (src/core/feast_backend_utils.jl:166-198 -> src/sparse/feast_sparse.jl:334-342); the :hip backend maps that default
+    to its converging Krylov configuration (COCG, Ritz warm start, inexact solves, real projection) and must return all
+    44 eigenpairs of cfg 3 at full size."""
+    A, B, lam = fo.cfg3_problem(50, 40, 25)
+    inside = lam[(lam >= 0.0) & (lam <= 0.1775)]
+    r = fk.feast(A, B, (0.0, 0.1775), M0=64, fpm=fpm_with(f2=16), engine=engine)
+    assert not np.iscomplexobj(r.q)
+    _cfg3_check(r, A, B, inside)
+    assert r.loop <= 12
+
+
+@pytest.mark.parametrize("aspect,cap", [(4000, 50), (100, 100)])
+def test_cfg3_bench_settings_full_size(engine, aspect, cap):
+    """The path bench.py times, at full size: COCG fp64 in sum mode (no per-node solution panels), Ritz warm start,
+    inner rtol 3e-2, balanced node lists, column groups by rule, on the bench's contour (Gauss nodes on the ellipse
+    fpm[18] = 4000) and on the reference's default circle."""
+    A, B, lam = fo.cfg3_problem(50, 40, 25)
+    inside = lam[(lam >= 0.0) & (lam <= 0.1775)]
+    r = fk.feast_hip_hermitian(engine, A, B, 0.0, 0.1775, 64, fpm_with(f2=16, f4=40, f18=aspect), solver="cocg", warm_start=True,
+                               inner_rtol=3e-2, solver_maxiter=cap, node_assignment="balanced", column_groups="auto",
+                               real_projection=True)
+    _cfg3_check(r, A, B, inside)
+    # sum mode really ran: the per-loop iteration log exists and no node needed more than the cap
+    assert all(max(per_loop) <= cap for per_loop in r.stats["node_iterations"])
+    G = r.q.conj().T @ (B @ r.q)
+    d = np.sqrt(np.abs(np.diag(G)))
+    assert np.abs(G / np.outer(d, d) - np.eye(44)).max() <= 1e-8
+
+
 def test_cfg3_full_size_properties(engine):
     """BASELINE cfg 3 at full size (N=50 000, nnz=341 500, 16 nodes, M0=64): closed-form spectrum,
     residual recomputed on the host, B-orthonormality of the Ritz vectors."""

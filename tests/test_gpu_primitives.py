@@ -6,8 +6,10 @@ import scipy.linalg as sla
 import scipy.sparse as sp
 
 import feast_oracle as fo
+from kat_util import cmat, cplx as kcplx, load_kats
 
 pytestmark = pytest.mark.gpu
+K = load_kats()
 
 
 def rand_block(N, m, seed, cplx=True):
@@ -123,16 +125,42 @@ def test_orthonormalize_rank_and_span(engine, N, m, true_rank):
 
 
 def test_orthonormalize_reference_kat(engine):
-    # rank-compress KAT of the reference (test/test_allocation_helpers.jl:274-292): 4x4, rank 2
+    # rank-compress KAT of the reference (test/test_allocation_helpers.jl:274-292): the 4x4 literal whose fourth column
+    # is 1e-15 (below the rank threshold max(sqrt(eps), eps*max(N, M0)) * |R_11|) and whose second is twice the first
+    k = K["qr_compress"]
     A, B = sparse_pair(4, 3)
     engine.set_problem(A, B)
-    src = np.array([[1, 2, 3, 4], [0, 1, 1, 2], [2, 5, 7, 10], [1, 1, 2, 2]], dtype=np.complex128)
-    ref_rank = np.linalg.matrix_rank(src)
+    src = cmat(k["src"])
+    assert src[0, 3] == 1e-15 and src[1, 3] == 1e-15j
     dQ = engine.upload(src)
-    rank = engine.orthonormalize(dQ, 4, np.sqrt(np.finfo(float).eps))
-    assert rank == ref_rank == fo.qr_compress(src, 4)[1]
+    rank = engine.orthonormalize(dQ, k["ncols"], np.sqrt(np.finfo(float).eps))
+    assert rank == k["expect_rank"] == fo.qr_compress(src, k["ncols"])[1] == 2
     Q = engine.download(dQ)[:, :rank]
-    assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= 1e-12 * np.linalg.norm(src)
+    assert np.abs(Q.conj().T @ Q - np.eye(rank)).max() < 1e-12
+    assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= k["span_tol"]
+
+
+def test_moment_kat_on_device(engine):
+    """Moment KAT of the reference (test/test_allocation_helpers.jl:219-265) through the device's want_moments path:
+    one contour node z = Zne[1], weight Wne[1], B = I and a dense A built so that (z - A)^-1 work = workc, the
+    literal solution block.  zAq must equal Wne[1]*(work'*workc) and zSq must equal Zne[1]*zAq."""
+    k = K["moment_accumulation"]
+    work, workc = cmat(k["work"]), cmat(k["workc"])
+    w, z = kcplx(k["Wne1"]), kcplx(k["Zne1"])
+    P = workc @ np.linalg.pinv(workc)
+    S = work @ np.linalg.pinv(workc) + 3.0 * (np.eye(3) - P)
+    A = z * np.eye(3) - S
+    engine.set_problem(A, None)
+    engine.set_contour(np.array([z]), np.array([w]), 1.0)
+    engine.set_real_projection(False)
+    engine.set_node_range(0, 1)
+    engine.set_solver("direct")
+    dP, status, _, zAq, zSq = engine.contour_apply(engine.upload(work), 2, None, want_moments=True)
+    assert int(status[0]) == 0
+    assert np.allclose(engine.download(dP, 2), w * workc, atol=1e-13)
+    assert np.allclose(zAq, cmat(k["expect_Aq"]), atol=1e-13) and np.allclose(zSq, cmat(k["expect_Bq"]), atol=1e-13)
+    oa, os_ = fo.node_moments(work, workc, w, z)
+    assert np.allclose(zAq, oa, atol=1e-13) and np.allclose(zSq, os_, atol=1e-13)
 
 
 @pytest.mark.parametrize("N,r,M", [(60, 6, 3), (400, 16, 16), (1500, 30, 11), (2500, 64, 44), (700, 100, 80), (1000, 129, 129)])

@@ -370,3 +370,25 @@ def test_eight_rank_gloo_bench_layout(tmp_path):
     one = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 1.2, 64, fpm, real_projection=True)
     assert (int(res[0][0]), int(res[0][1])) == (one.info, one.M) == (0, len(inside)) and abs(int(res[0][2]) - one.loop) <= 1
     assert np.allclose(res[0][4:4 + one.M], inside, atol=1e-10)
+
+
+def test_feastdefault_mirrors_reference():
+    """feastdefault! (src/core/feast_parameters.jl:41-386): defaults (KAT from test/runtests.jl: fpm[1..4] = 0, 8, 12, 20),
+    the "<= 0" resets of fpm[2], fpm[4], fpm[8] (:103, :130, :161), fpm[30] untouched, range errors."""
+    fpm = fk.feastdefault(fk.feastinit())
+    for i, v in K["fpm_defaults"].items():
+        assert fpm[int(i)] == v
+    assert fpm[8] == 16 and fpm[18] == 100 and fpm[16] == 0 and fpm[30] == -111
+    assert all(fpm[i] == 0 for i in list(range(20, 29)) + list(range(33, 36)) + list(range(50, 59)) + list(range(61, 64)))
+    fpm = fk.feastinit(); fpm[2], fpm[4], fpm[8] = 0, -3, 0
+    fk.feastdefault(fpm)
+    assert (fpm[2], fpm[4], fpm[8]) == (8, 20, 16)
+    fpm = fk.feastinit(); fpm[2] = 16; fpm[18] = 4000
+    fk.feastdefault(fpm)
+    assert fpm[2] == 16 and fpm[18] == 4000
+    for slot, val in ((2, 21), (3, 17), (16, 3), (8, 1), (18, -1), (19, 181), (1, 2)):
+        fpm = fk.feastinit(); fpm[slot] = val
+        with pytest.raises(ValueError):
+            fk.feastdefault(fpm)
+    fpm = fk.feastinit(); fpm[2] = 24
+    assert fk.feastdefault(fpm)[2] == 24            # allowed large Gauss rule

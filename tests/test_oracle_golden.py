@@ -45,8 +45,17 @@ def test_moment_kat():
     k = K["moment_accumulation"]
     work, workc = cmat(k["work"]), cmat(k["workc"])
     w, z = cplx(k["Wne1"]), cplx(k["Zne1"])
-    Aq = w * (work.conj().T @ workc)
-    assert np.allclose(Aq, cmat(k["expect_Aq"])) and np.allclose(z * Aq, cmat(k["expect_Bq"]))
+    Aq, Bq = fo.node_moments(work, workc, w, z)        # the routine every variant-B driver of the oracle goes through
+    assert np.allclose(Aq, cmat(k["expect_Aq"]), rtol=1e-14, atol=0) and np.allclose(Bq, cmat(k["expect_Bq"]), rtol=1e-14, atol=0)
+    # and through a driver: one node, B = I, A chosen so that (z - A)^-1 work = workc -- the per-node worker must
+    # return exactly these moments (real parts, weight 2w: src/parallel/feast_parallel.jl:717-751)
+    P = workc @ np.linalg.pinv(workc)
+    S = work @ np.linalg.pinv(workc) + 3.0 * (np.eye(3) - P)
+    A = z * np.eye(3) - S
+    Y = np.linalg.solve(z * np.eye(3) - A, work)
+    assert np.allclose(Y, workc, atol=1e-13)
+    a2, s2 = fo.node_moments(work, Y, w, z)
+    assert np.allclose(a2, cmat(k["expect_Aq"]), atol=1e-13) and np.allclose(s2, cmat(k["expect_Bq"]), atol=1e-13)
 
 
 def test_qr_compress_kat():
