@@ -137,29 +137,29 @@ static void shm_unmap_peers(fh_comm* c) {
     }
 }
 
-static int shm_grow(feasthip_ctx* h, fh_comm* c, size_t bytes) {
-    // every rank calls with the same byte count (the reduction is collective), so they all take this branch together
-    if (!shm_barrier(c)) { h->last_error = "comm(shm): peers did not reach the resize barrier"; return FEASTHIP_ERROR_INTERNAL; }
-    shm_unmap_peers(c);
-    if (c->staging) { hipFree(c->staging); c->staging = nullptr; }
-    size_t cap = std::max<size_t>(bytes, 1 << 20);
-    FH_CHECK(hipMalloc(&c->staging, cap));
+// One staging buffer per rank, allocated and exchanged ONCE at init (re-exporting a re-allocated buffer was seen to
+// fail with hipIpcGetMemHandle: invalid argument); larger reductions stream through it in chunks.
+static int shm_setup_staging(feasthip_ctx* h, fh_comm* c) {
+    auto fail = [&](const std::string& msg) { c->seg->failed.store(1); h->last_error = msg; return (int)FEASTHIP_ERROR_INTERNAL; };
+    size_t cap = 32u << 20;
+    if (getenv("FEASTHIP_COMM_STAGING_MB")) cap = (size_t)std::max(1, atoi(getenv("FEASTHIP_COMM_STAGING_MB"))) << 20;
+    hipError_t e = hipMalloc(&c->staging, cap);
+    if (e != hipSuccess) return fail(std::string("comm(shm): hipMalloc(staging): ") + hipGetErrorString(e));
     c->staging_bytes = cap;
-    FH_CHECK(hipIpcGetMemHandle(&c->seg->handle[c->rank], c->staging));
+    e = hipIpcGetMemHandle(&c->seg->handle[c->rank], c->staging);
+    if (e != hipSuccess) return fail(std::string("comm(shm): hipIpcGetMemHandle: ") + hipGetErrorString(e) +
+                                     " (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set for dmabuf IPC)");
     c->seg->bytes[c->rank] = cap;
     if (!shm_barrier(c)) { h->last_error = "comm(shm): peers did not publish their staging buffers"; return FEASTHIP_ERROR_INTERNAL; }
     for (int r = 0; r < c->nranks; ++r) {
         if (r == c->rank) { c->peer[r] = c->staging; continue; }
-        hipError_t e = hipIpcOpenMemHandle(&c->peer[r], c->seg->handle[r], hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) {
-            c->seg->failed.store(1);
-            h->last_error = std::string("comm(shm): hipIpcOpenMemHandle: ") + hipGetErrorString(e) +
-                            " (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set for dmabuf IPC)";
-            return FEASTHIP_ERROR_INTERNAL;
-        }
+        e = hipIpcOpenMemHandle(&c->peer[r], c->seg->handle[r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(std::string("comm(shm): hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        c->staging_bytes = std::min<size_t>(c->staging_bytes, (size_t)c->seg->bytes[r]);
     }
-    if (!c->d_peers) FH_CHECK(hipMalloc((void**)&c->d_peers, FH_SHM_MAX_RANKS * sizeof(double*)));
-    FH_CHECK(hipMemcpy(c->d_peers, c->peer, c->nranks * sizeof(double*), hipMemcpyHostToDevice));
+    e = hipMalloc((void**)&c->d_peers, FH_SHM_MAX_RANKS * sizeof(double*));
+    if (e == hipSuccess) e = hipMemcpy(c->d_peers, c->peer, c->nranks * sizeof(double*), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(std::string("comm(shm): peer table: ") + hipGetErrorString(e));
     if (!shm_barrier(c)) { h->last_error = "comm(shm): peers did not map the staging buffers"; return FEASTHIP_ERROR_INTERNAL; }
     return 0;
 }
@@ -186,7 +186,7 @@ int fh_comm_destroy(feasthip_ctx* h) {
     hipStreamSynchronize(h->stream);
     if (c->transport == FEASTHIP_COMM_RCCL && c->nccl) rccl()->CommDestroy(c->nccl);
     if (c->transport == FEASTHIP_COMM_SHM && c->seg) {
-        shm_barrier(c);                               // nobody unmaps while a peer may still read
+        if (!c->seg->failed.load()) shm_barrier(c);  // nobody unmaps while a peer may still read
         shm_unmap_peers(c);
         if (c->staging) hipFree(c->staging);
         if (c->d_peers) hipFree((void*)c->d_peers);
@@ -256,6 +256,8 @@ extern "C" int feasthip_comm_init_rank(feasthip_handle h, int nranks, int rank, 
         h->comm = c;
         if (!shm_barrier(c)) { h->last_error = "comm(shm): attach barrier failed"; return FEASTHIP_ERROR_INTERNAL; }
         if (rank == 0) shm_unlink(name);
+        int rc = shm_setup_staging(h, c);
+        if (rc) { fh_comm_destroy(h); return rc; }
         return 0;
     } else {
         h->last_error = "comm_init_rank: transport must be FEASTHIP_COMM_AUTO, _RCCL or _SHM";
@@ -289,16 +291,21 @@ int fh_comm_allreduce_sum(feasthip_ctx* h, double* d, size_t count) {
         }
         return 0;
     }
-    int rc;
-    const size_t bytes = count * sizeof(double);
-    if (bytes > c->staging_bytes && (rc = shm_grow(h, c, bytes))) return rc;
-    FH_CHECK(hipMemcpyAsync(c->staging, d, bytes, hipMemcpyDeviceToDevice, h->stream));
-    FH_CHECK(hipStreamSynchronize(h->stream));
-    if (!shm_barrier(c)) { h->last_error = "comm(shm): a peer failed or timed out before the reduction"; return FEASTHIP_ERROR_INTERNAL; }
-    const int nblk = (int)std::min<size_t>(2048, (count + 255) / 256);
-    hipLaunchKernelGGL(k_sum_peers, dim3(nblk), dim3(256), 0, h->stream, (const double* const*)c->d_peers, c->nranks, d, count);
-    FH_CHECK(hipStreamSynchronize(h->stream));
-    if (!shm_barrier(c)) { h->last_error = "comm(shm): a peer failed or timed out after the reduction"; return FEASTHIP_ERROR_INTERNAL; }
+    // stream the buffer through the staging area in chunks: stage -> barrier -> every rank sums the peers' chunks in
+    // rank order -> barrier (nobody overwrites its staging while a peer may still read it)
+    auto fail = [&](const char* msg) { c->seg->failed.store(1); h->last_error = msg; return (int)FEASTHIP_ERROR_INTERNAL; };
+    const size_t chunk = c->staging_bytes / sizeof(double);
+    for (size_t off = 0; off < count; off += chunk) {
+        const size_t n = std::min(chunk, count - off);
+        if (hipMemcpyAsync(c->staging, d + off, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess)
+            return fail("comm(shm): staging copy failed");
+        if (!shm_barrier(c)) { h->last_error = "comm(shm): a peer failed or timed out before the reduction"; return FEASTHIP_ERROR_INTERNAL; }
+        const int nblk = (int)std::min<size_t>(2048, (n + 255) / 256);
+        hipLaunchKernelGGL(k_sum_peers, dim3(nblk), dim3(256), 0, h->stream, (const double* const*)c->d_peers, c->nranks, d + off, n);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("comm(shm): reduction kernel failed");
+        if (!shm_barrier(c)) { h->last_error = "comm(shm): a peer failed or timed out after the reduction"; return FEASTHIP_ERROR_INTERNAL; }
+    }
     return 0;
 }
 

@@ -50,7 +50,8 @@ def test_rccl_single_rank(engine):
 
 
 WORKER = r'''
-import os, sys, time
+import os, sys, time, faulthandler
+faulthandler.dump_traceback_later(240, exit=True)      # a wedged collective must not hang the suite
 sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
 import numpy as np, torch
 import feast_oracle as fo, feastkit_jl_amd as fk
@@ -144,7 +145,8 @@ def test_shared_device_ranks_through_ctypes(engine, tmp_path, world):
 
 
 CFG3 = r'''
-import os, sys, time
+import os, sys, time, faulthandler
+faulthandler.dump_traceback_later(600, exit=True)
 sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
 import numpy as np, torch
 import feastkit_jl_amd as fk
