@@ -771,158 +771,138 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
 // restarted GMRES(m) on panels -- the reference's iterative solver
 // (solve_shifted_iterative!, src/sparse/feast_sparse.jl:164-203; Krylov.jl gmres with
 // restart=true, memory=m, zero initial guess unless X holds one, stop ||r|| <= atol + rtol ||r0||).
-// All columns of a node advance in lock-step through modified Gram-Schmidt Arnoldi; the panel
-// operations run on the device (operator, per-column dots, axpys), the (m+1) x m Hessenberg
-// least-squares problems per column are kept on the host.  Provided for API completeness
-// (`solver = :gmres`): it is host-synchronous and not performance-tuned -- the batched
-// BiCG-family solvers above are the fast path.
+// Device resident (fh_gmres.hip): all columns of all local nodes advance in lock-step; basis panels, Hessenberg
+// columns, Givens rotations and the per-column stop test live on the device.  The host only queues kernels: it
+// looks at the device's published progress word without blocking to stop queueing once every column has converged
+// inside a cycle, and reads the true-residual check once per restart cycle.
 // ---------------------------------------------------------------------------------------
-static int fh_gmres(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, cplx* X,
+static int fh_gmres(feasthip_ctx* h, int ld, int m, int nodes_all, const std::vector<cplx>& z, const cplx* RHS, cplx* X,
                     size_t stride, fh_solve_result& res) {
     const int N = (int)fh_N(h);
     const size_t panel = (size_t)N * ld;
     const int mr = std::max(h->restart, 2);
     int rc;
     void* p;
-    if ((rc = fh_get_buf(h, "gm_V", (size_t)(mr + 2) * panel * sizeof(cplx), &p))) return rc;
-    cplx* V = (cplx*)p;                       // V_0 .. V_mr, then W
-    cplx* W = V + (size_t)(mr + 1) * panel;
-    const int nblk_vec = fh_vec_nblk(N, ld);
-    if ((rc = fh_get_buf(h, "gm_part", (size_t)std::max(nblk_vec, fh_op_nblk(h, ld)) * ld * sizeof(cplx), &p))) return rc;
-    cplx* part = (cplx*)p;
-    if ((rc = fh_get_buf(h, "gm_dots", (size_t)ld * sizeof(cplx), &p))) return rc;
-    cplx* ddots = (cplx*)p;
-    std::vector<cplx> dots(ld), coef(ld);
-    res.status.assign(nodes, 0);
-    auto dot_cols = [&](const cplx* U, const cplx* Vv) -> int {
-        fh_launch_dot_cols(U, Vv, N, ld, part, ddots, h->stream);
-        if (hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return 7;
-        return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : 7;
-    };
-    for (int e = 0; e < nodes; ++e) {
-        cplx* Xe = X + (size_t)e * stride;
-        std::vector<cplx> ca(ld, cmake(-1, 0)), cb(ld, z[e]);
+    res.status.assign(nodes_all, 0);
+    // node batches: the basis costs (mr + 2) panels per node
+    const size_t per_node = (size_t)(mr + 2) * panel * sizeof(cplx);
+    size_t budget = (size_t)48 << 30;
+    if (getenv("FH_GMRES_BUDGET_MB")) budget = (size_t)std::max(1, atoi(getenv("FH_GMRES_BUDGET_MB"))) << 20;
+    const int nbatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)nodes_all, budget / std::max<size_t>(per_node, 1)));
+    const int nblk_vec = fh_kry_nblk(N, ld, nbatch);
+    const int nblk_op = fh_op_nblk(h, ld);
+    for (int e0 = 0; e0 < nodes_all; e0 += nbatch) {
+        const int nodes = std::min(nbatch, nodes_all - e0);
+        const size_t nl = (size_t)nodes * ld;
+        if ((rc = fh_get_buf(h, "gm_V", (size_t)nodes * (mr + 1) * panel * sizeof(cplx), &p))) return rc;
+        cplx* V = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gm_W", (size_t)nodes * panel * sizeof(cplx), &p))) return rc;
+        cplx* W = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gm_part", fh_gm_partial_elems(mr, nblk_vec, nodes, ld) * sizeof(cplx), &p))) return rc;
+        cplx* part = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gm_npart", (size_t)nodes * std::max(nblk_vec, nblk_op) * ld * sizeof(cplx), &p))) return rc;
+        cplx* npart = (cplx*)p;
+        const size_t hsz = nl * (size_t)(mr + 1) * mr;
+        if ((rc = fh_get_buf(h, "gm_small_c", (hsz + nl * (mr + 1) * 2 + nl * mr * 3) * sizeof(cplx), &p))) return rc;
+        cplx* sc = (cplx*)p;
+        if ((rc = fh_get_buf(h, "gm_small_d", nl * 4 * sizeof(double), &p))) return rc;
+        double* sd = (double*)p;
+        if ((rc = fh_get_buf(h, "gm_small_i", (nl * 4 + nodes) * sizeof(int), &p))) return rc;
+        int* si = (int*)p;
+        fh_gmres_args ga;
+        ga.N = N; ga.mr = mr; ga.panel = panel; ga.V = V; ga.v_node_stride = (size_t)(mr + 1) * panel; ga.W = W;
+        ga.partial = part; ga.npartial = npart;
+        ga.H = sc; ga.hcur = ga.H + hsz; ga.g = ga.hcur + nl * (mr + 1); ga.cs = ga.g + nl * (mr + 1); ga.sn = ga.cs + nl * mr;
+        ga.y = ga.sn + nl * mr;
+        ga.inv = sd; ga.r0norm = sd + nl; ga.target = sd + 2 * nl; ga.rnorm = sd + 3 * nl;
+        ga.active = si; ga.iters = si + nl; ga.status = si + 2 * nl; ga.kdim = si + 3 * nl; ga.node_active = si + 4 * nl;
+        FH_CHECK(hipMemsetAsync(sc, 0, hsz * sizeof(cplx), h->stream));
+
+        std::vector<cplx> ca(nl, cmake(-1, 0)), cb(nl);
+        for (int e = 0; e < nodes; ++e) for (int c = 0; c < ld; ++c) cb[(size_t)e * ld + c] = z[e0 + e];
         cplx *dca, *dcb;
         if ((rc = fh_upload_coefs(h, "gm_coefA", ca, &dca))) return rc;
         if ((rc = fh_upload_coefs(h, "gm_coefB", cb, &dcb))) return rc;
+        cplx* Xb = X + (size_t)e0 * stride;
         fh_op_call oc;
-        oc.m = m; oc.uniform_coef = 1; oc.coefA = dca; oc.coefB = dcb; oc.nodes = 1;
-        oc.partial1 = nullptr; oc.partial2 = nullptr; oc.U = nullptr; oc.u_stride = 0; oc.node_active = nullptr;
-        oc.x_stride = 0; oc.y_stride = 0; oc.b_stride = 0; oc.dot_mode = 0;
-        std::vector<double> target(m, 0.0), r0n(m, 0.0), rn(m, 0.0);
-        std::vector<int> its(m, 0);
-        std::vector<char> done(m, 0);
-        bool first = true;
-        int total_it = 0;
-        while (total_it < h->maxit) {
-            // r = b - S x ; beta = ||r||
-            oc.X = Xe; oc.Y = V; oc.Bvec = RHS;
-            fh_apply_operator(h, ld, oc);
+        oc.m = m; oc.uniform_coef = 1; oc.coefA = dca; oc.coefB = dcb; oc.nodes = nodes; oc.prec = 64;
+        oc.partial1 = nullptr; oc.partial2 = npart; oc.U = nullptr; oc.u_stride = 0;
+
+        int total_it = 0, first = 1;
+        unsigned tag = 0;
+        *h->h_progress = 0ull;
+        auto seen = [&](unsigned& st, unsigned& cnt) { unsigned long long w = *h->h_progress; st = (unsigned)(w >> 32); cnt = (unsigned)(w & 0xffffffffull); };
+        while (true) {
+            // true residual r = b - S x (into W), ||r|| per column, activity from the stop test
+            oc.X = Xb; oc.x_stride = stride; oc.Y = W; oc.y_stride = panel; oc.Bvec = RHS; oc.b_stride = 0; oc.dot_mode = 3; oc.node_active = nullptr;
+            const int nb_norm = fh_apply_operator(h, ld, oc);
             res.op_calls += 1;
-            if (dot_cols(V, V)) return FEASTHIP_ERROR_INTERNAL;
-            std::vector<double> beta(m);
-            bool any = false;
-            for (int c = 0; c < m; ++c) {
-                beta[c] = std::sqrt(dots[c].x);
-                rn[c] = beta[c];
-                if (first) { r0n[c] = beta[c]; target[c] = h->atol + h->rtol * beta[c]; }
-                if (!(beta[c] > target[c]) || !std::isfinite(beta[c])) done[c] = 1;
-                if (!done[c]) any = true;
-            }
-            first = false;
-            if (!any) break;
-            for (int c = 0; c < ld; ++c) coef[c] = (c < m && !done[c] && beta[c] > 0) ? cmake(1.0 / beta[c], 0) : cmake(0, 0);
-            cplx* dco;
-            if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
-            fh_launch_scale_cols(V, dco, N, ld, h->stream);               // v_0 = r / beta (0 for finished columns)
-            // per-column Hessenberg data
-            std::vector<std::vector<cplx>> H(m, std::vector<cplx>((size_t)(mr + 1) * mr, cmake(0, 0)));
-            std::vector<std::vector<cplx>> cs(m, std::vector<cplx>(mr)), sn(m, std::vector<cplx>(mr)), g(m, std::vector<cplx>(mr + 1, cmake(0, 0)));
-            std::vector<int> kc(m, 0);             // Krylov dimension used by each column in this cycle
-            for (int c = 0; c < m; ++c) g[c][0] = cmake(beta[c], 0);
-            int k = 0;
-            for (; k < mr && total_it < h->maxit; ++k) {
-                cplx* Vk = V + (size_t)k * panel;
-                oc.X = Vk; oc.Y = W; oc.Bvec = nullptr;
-                fh_apply_operator(h, ld, oc);                               // w = S v_k
+            fh_launch_gm_start(ga, ld, nb_norm, nodes, first, h->rtol, h->atol, m, h->stream);
+            first = 0;
+            ++tag;
+            fh_launch_publish_progress(ga.node_active, nodes, h->d_progress, tag, h->stream);
+            FH_CHECK(hipStreamSynchronize(h->stream));           // the one host round trip per restart cycle
+            unsigned st = 0, cnt = 0;
+            seen(st, cnt);
+            if (cnt == 0 || total_it >= h->maxit) break;
+            fh_launch_gm_scale_store(ga, ld, W, panel, 0, nblk_vec, nodes, h->stream);           // v_0 = r / beta
+            int ksteps = 0;
+            const unsigned tag0 = tag;
+            for (int k = 0; k < mr && total_it < h->maxit; ++k) {
+                oc.X = V + (size_t)k * panel; oc.x_stride = ga.v_node_stride; oc.Y = W; oc.y_stride = panel; oc.Bvec = nullptr;
+                oc.dot_mode = 0; oc.node_active = ga.node_active; oc.partial2 = nullptr;
+                fh_apply_operator(h, ld, oc);                                                  // w = S v_k
+                oc.partial2 = npart;
                 res.op_calls += 1;
-                for (int i = 0; i <= k; ++i) {                                // modified Gram-Schmidt
-                    cplx* Vi = V + (size_t)i * panel;
-                    if (dot_cols(Vi, W)) return FEASTHIP_ERROR_INTERNAL;
-                    for (int c = 0; c < ld; ++c) coef[c] = (c < m && !done[c]) ? dots[c] : cmake(0, 0);
-                    for (int c = 0; c < m; ++c) if (!done[c]) H[c][(size_t)k * (mr + 1) + i] = dots[c];
-                    if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
-                    fh_launch_axpy_cols(W, Vi, dco, N, ld, h->stream);     // w -= h_ik v_i
-                }
-                if (dot_cols(W, W)) return FEASTHIP_ERROR_INTERNAL;
-                bool any_active = false;
-                for (int c = 0; c < ld; ++c) coef[c] = cmake(0, 0);
-                for (int c = 0; c < m; ++c) {
-                    if (done[c]) continue;
-                    double hk1 = std::sqrt(dots[c].x);
-                    cplx* Hc = &H[c][(size_t)k * (mr + 1)];
-                    Hc[k + 1] = cmake(hk1, 0);
-                    for (int i = 0; i < k; ++i) {                            // previous rotations
-                        cplx t = cadd(cmul(cs[c][i], Hc[i]), cmul(sn[c][i], Hc[i + 1]));
-                        Hc[i + 1] = cadd(cmul(cmake(-sn[c][i].x, sn[c][i].y), Hc[i]), cmul(cs[c][i], Hc[i + 1]));
-                        Hc[i] = t;
+                fh_prof_begin(h, "gmres_ortho");
+                fh_launch_gm_orthogonalize(ga, ld, k, nblk_vec, nodes, h->stream);             // CGS2 against v_0..v_k
+                fh_launch_gm_givens(ga, ld, k, nblk_vec, nodes, h->stream);
+                fh_launch_gm_scale_store(ga, ld, W, panel, k + 1, nblk_vec, nodes, h->stream); // v_{k+1} = w / h_{k+1,k}
+                fh_prof_end(h);
+                ++tag;
+                fh_launch_publish_progress(ga.node_active, nodes, h->d_progress, tag, h->stream);
+                ++ksteps; ++total_it;
+                // non-blocking look at the device's progress: stop queueing steps once every column has converged
+                seen(st, cnt);
+                if (st > tag0 && cnt == 0) break;
+                if (tag - st > 6) {                       // stay at most six steps ahead of the device
+                    for (unsigned spins = 1; tag - st > 6; ++spins) {
+                        std::this_thread::sleep_for(std::chrono::microseconds(100));
+                        seen(st, cnt);
+                        if ((spins & 2047u) == 0) {
+                            const hipError_t q = hipStreamQuery(h->stream);
+                            if (q != hipSuccess && q != hipErrorNotReady) {
+                                h->last_error = std::string("device queue failed inside a GMRES cycle: ") + hipGetErrorString(q);
+                                return FEASTHIP_ERROR_INTERNAL;
+                            }
+                        }
                     }
-                    cplx a = Hc[k], b = Hc[k + 1];
-                    double aa = std::sqrt(cabs2(a)), den = std::sqrt(cabs2(a) + cabs2(b));
-                    if (den == 0.0) { cs[c][k] = cmake(1, 0); sn[c][k] = cmake(0, 0); }
-                    else if (aa == 0.0) { cs[c][k] = cmake(0, 0); sn[c][k] = cmake(1, 0); }
-                    else {
-                        cs[c][k] = cmake(aa / den, 0);
-                        sn[c][k] = cscale(cmul(cscale(a, 1.0 / aa), cconj(b)), 1.0 / den);
-                    }
-                    Hc[k] = cadd(cmul(cs[c][k], a), cmul(sn[c][k], b));
-                    Hc[k + 1] = cmake(0, 0);
-                    g[c][k + 1] = cmul(cmake(-sn[c][k].x, sn[c][k].y), g[c][k]);
-                    g[c][k] = cmul(cs[c][k], g[c][k]);
-                    its[c] += 1;
-                    kc[c] = k + 1;
-                    rn[c] = std::sqrt(cabs2(g[c][k + 1]));
-                    if (!(rn[c] > target[c]) || hk1 == 0.0) done[c] = 1;     // converged (or lucky breakdown)
-                    else { any_active = true; coef[c] = cmake(1.0 / hk1, 0); }
+                    if (st > tag0 && cnt == 0) break;
                 }
-                total_it += 1;
-                if (!any_active) { ++k; break; }
-                if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
-                fh_launch_scale_cols(W, dco, N, ld, h->stream);              // v_{k+1} = w / h_{k+1,k}
-                FH_CHECK(hipMemcpyAsync(V + (size_t)(k + 1) * panel, W, panel * sizeof(cplx), hipMemcpyDeviceToDevice, h->stream));
             }
-            // x += V y, y from the triangular systems
-            std::vector<std::vector<cplx>> y(m);
-            int kmax = 0;
+            fh_launch_gm_finish_cycle(ga, ld, Xb, stride, ksteps, nblk_vec, nodes, h->stream);   // x += V y
+        }
+        // bookkeeping
+        std::vector<int> iters(nl), status(nl), active(nl);
+        std::vector<double> rnorm(nl), r0(nl), target(nl);
+        FH_CHECK(hipMemcpy(iters.data(), ga.iters, nl * sizeof(int), hipMemcpyDeviceToHost));
+        FH_CHECK(hipMemcpy(status.data(), ga.status, nl * sizeof(int), hipMemcpyDeviceToHost));
+        FH_CHECK(hipMemcpy(active.data(), ga.active, nl * sizeof(int), hipMemcpyDeviceToHost));
+        FH_CHECK(hipMemcpy(rnorm.data(), ga.rnorm, nl * sizeof(double), hipMemcpyDeviceToHost));
+        FH_CHECK(hipMemcpy(r0.data(), ga.r0norm, nl * sizeof(double), hipMemcpyDeviceToHost));
+        FH_CHECK(hipMemcpy(target.data(), ga.target, nl * sizeof(double), hipMemcpyDeviceToHost));
+        for (int e = 0; e < nodes; ++e) {
+            int mx = 0, stn = 0;
             for (int c = 0; c < m; ++c) {
-                int kk = kc[c];
-                kmax = std::max(kmax, kk);
-                y[c].assign(kk, cmake(0, 0));
-                for (int i = kk - 1; i >= 0; --i) {
-                    cplx sacc = g[c][i];
-                    for (int j = i + 1; j < kk; ++j) sacc = csub(sacc, cmul(H[c][(size_t)j * (mr + 1) + i], y[c][j]));
-                    cplx d = H[c][(size_t)i * (mr + 1) + i];
-                    y[c][i] = cabs2(d) > 0 ? cdiv(sacc, d) : cmake(0, 0);
-                }
+                const size_t i = (size_t)e * ld + c;
+                mx = std::max(mx, iters[i]);
+                res.col_iters.push_back(iters[i]);
+                if (active[i] || !std::isfinite(rnorm[i]) || rnorm[i] > target[i]) stn = FEASTHIP_ERROR_NO_CONVERGENCE;
+                if (r0[i] > 0) res.max_rel_res = std::max(res.max_rel_res, rnorm[i] / r0[i]);
             }
-            for (int i = 0; i < kmax; ++i) {
-                for (int c = 0; c < ld; ++c) coef[c] = (c < m && i < (int)y[c].size()) ? cmake(-y[c][i].x, -y[c][i].y) : cmake(0, 0);
-                if ((rc = fh_upload_coefs(h, "gm_coef", coef, &dco))) return rc;
-                fh_launch_axpy_cols(Xe, V + (size_t)i * panel, dco, N, ld, h->stream);   // x -= (-y_i) v_i
-            }
-            // columns flagged done inside the cycle are re-examined with the true residual next cycle
-            for (int c = 0; c < m; ++c) done[c] = 0;
+            res.iters_sum += mx; res.node_iters.push_back(mx); res.max_iters = std::max(res.max_iters, mx);
+            res.status[e0 + e] = stn;
         }
-        FH_CHECK(hipStreamSynchronize(h->stream));
-        int mx = 0, st = 0;
-        for (int c = 0; c < m; ++c) {
-            mx = std::max(mx, its[c]);
-            res.col_iters.push_back(its[c]);
-            if (rn[c] > target[c]) st = FEASTHIP_ERROR_NO_CONVERGENCE;
-            if (r0n[c] > 0) res.max_rel_res = std::max(res.max_rel_res, rn[c] / r0n[c]);
-        }
-        res.iters_sum += mx; res.node_iters.push_back(mx); res.max_iters = std::max(res.max_iters, mx);
-        res.status[e] = st;
     }
     return 0;
 }
@@ -998,8 +978,19 @@ static int fh_dense_lu_refined(feasthip_ctx* h, int ld, int m, int nodes, const 
     return 0;
 }
 
+// Moment matrices of a sweep that is wider than one panel (variant B with M0 > 64): the panel call below holds the
+// solution block Y_e of ITS columns only, so it adds the block column  w_e Q_all^H Y_e  (all rows, its columns) to the
+// host accumulators; the caller uploads them once every panel is done.
+struct fh_moment_ctx {
+    const cplx* dQ_all = nullptr;       // N x m_all column-major device pointer (the whole subspace)
+    int m_all = 0, col0 = 0;            // total width, first column of the current panel
+    std::vector<cplx>* aq = nullptr;    // m_all x m_all column-major host accumulators
+    std::vector<cplx>* sq = nullptr;
+};
+
 static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
-                                  cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+                                  cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats,
+                                  const fh_moment_ctx* mom = nullptr) {
     int rc = fh_check_problem(h, m64);
     if (rc) return rc;
     if (h->zne.empty()) { h->last_error = "no contour set"; return FEASTHIP_ERROR_FPM; }
@@ -1089,7 +1080,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
         fh_solve_result sr;
         // sum mode: only Q_proj is wanted (no moments), so the per-node solutions are never formed
-        if (h->solver == FEASTHIP_SOLVER_COCG && !dzAq && !dzSq && h->sum_mode) {
+        if (h->solver == FEASTHIP_SOLVER_COCG && !dzAq && !dzSq && !mom && h->sum_mode) {
             if ((rc = fh_get_buf(h, "ca_acc", panel * sizeof(cplx), &p))) return rc;
             sum_acc = (cplx*)p;
             FH_CHECK(hipMemsetAsync(sum_acc, 0, panel * sizeof(cplx), h->stream));
@@ -1146,29 +1137,45 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream);
 
     // optional moments (variant B): zAq += w_e Q^H Y_e ; zSq += w_e z_e Q^H Y_e
-    if (dzAq || dzSq) {
+    if (dzAq || dzSq || mom) {
         if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
         cplx* gw = (cplx*)p;
         if ((rc = fh_get_buf(h, "gram_G", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
         cplx* G = (cplx*)p;
-        std::vector<cplx> Gh((size_t)ld * ld), aq((size_t)m * m, cmake(0, 0)), sq((size_t)m * m, cmake(0, 0));
-        for (int e = 0; e < nodes; ++e) {
-            fh_prof_begin(h, "gram");
-            fh_launch_gram(Qp, Y + (size_t)e * panel, N, ld, 0, gw, G, h->stream);
-            fh_prof_end(h);
-            FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
-            FH_CHECK(hipStreamSynchronize(h->stream));
-            cplx wz = cmul(w[e], z[e]);
-            for (int c2 = 0; c2 < m; ++c2)
-                for (int c1 = 0; c1 < m; ++c1) {
-                    cplx g = Gh[(size_t)c2 * ld + c1];
-                    cfma(aq[(size_t)c2 * m + c1], w[e], g);
-                    cfma(sq[(size_t)c2 * m + c1], wz, g);
-                }
+        const int m_all = mom ? mom->m_all : m, col0 = mom ? mom->col0 : 0;
+        std::vector<cplx> Gh((size_t)ld * ld), aq_local, sq_local;
+        if (!mom) { aq_local.assign((size_t)m * m, cmake(0, 0)); sq_local.assign((size_t)m * m, cmake(0, 0)); }
+        std::vector<cplx>& aq = mom ? *mom->aq : aq_local;
+        std::vector<cplx>& sq = mom ? *mom->sq : sq_local;
+        cplx* Qrow = Qp;                       // row block of Q in panel layout (the panel's own columns when not wide)
+        if (mom && (rc = fh_get_buf(h, "ca_Qrow", panel * sizeof(cplx), &p))) return rc;
+        if (mom) Qrow = (cplx*)p;
+        for (int r0 = 0; r0 < m_all; r0 += ld) {
+            const int mr_ = std::min(ld, m_all - r0);
+            if (mom) {
+                fh_launch_to_panel(mom->dQ_all + (size_t)r0 * N, N, N, mr_, Qrow, ld, h->stream);
+            }
+            for (int e = 0; e < nodes; ++e) {
+                fh_prof_begin(h, "gram");
+                fh_launch_gram(Qrow, Y + (size_t)e * panel, N, ld, 0, gw, G, h->stream);
+                fh_prof_end(h);
+                FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
+                FH_CHECK(hipStreamSynchronize(h->stream));
+                cplx wz = cmul(w[e], z[e]);
+                for (int c2 = 0; c2 < m; ++c2)
+                    for (int c1 = 0; c1 < mr_; ++c1) {
+                        cplx g = Gh[(size_t)c2 * ld + c1];
+                        cfma(aq[(size_t)(col0 + c2) * m_all + r0 + c1], w[e], g);
+                        cfma(sq[(size_t)(col0 + c2) * m_all + r0 + c1], wz, g);
+                    }
+            }
+            if (!mom) break;
         }
-        if (h->real_projection) for (size_t i = 0; i < aq.size(); ++i) { aq[i].y = 0.0; sq[i].y = 0.0; }
-        if (dzAq) FH_CHECK(hipMemcpyAsync(dzAq, aq.data(), aq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
-        if (dzSq) FH_CHECK(hipMemcpyAsync(dzSq, sq.data(), sq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+        if (!mom) {
+            if (h->real_projection) for (size_t i = 0; i < aq.size(); ++i) { aq[i].y = 0.0; sq[i].y = 0.0; }
+            if (dzAq) FH_CHECK(hipMemcpyAsync(dzAq, aq.data(), aq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+            if (dzSq) FH_CHECK(hipMemcpyAsync(dzSq, sq.data(), sq.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+        }
     }
     FH_CHECK(hipStreamSynchronize(h->stream));
     if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = status[e];
@@ -1190,8 +1197,15 @@ static int fh_contour_apply_local(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     if (m64 <= FH_MAX_LD) return fh_contour_apply_panel(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
     int rc = fh_check_problem(h, m64, 1);
     if (rc) return rc;
-    if (dzAq || dzSq) { h->last_error = "contour_apply: moment matrices need m <= 64"; return FEASTHIP_ERROR_M0; }
     const int m = (int)m64, N = (int)fh_N(h), nodes = h->node_count;
+    // moment matrices of a wide sweep: block columns gathered on the host, uploaded after the last panel
+    std::vector<cplx> aq_all, sq_all;
+    fh_moment_ctx mom;
+    const bool want_mom = dzAq || dzSq;
+    if (want_mom) {
+        aq_all.assign((size_t)m * m, cmake(0, 0)); sq_all.assign((size_t)m * m, cmake(0, 0));
+        mom.dQ_all = dQ; mom.m_all = m; mom.aq = &aq_all; mom.sq = &sq_all;
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     std::vector<int> ns(std::max(nodes, 1), 0), node_it(nodes, 0), col_it((size_t)nodes * m, 0);
     if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = 0;
@@ -1202,8 +1216,9 @@ static int fh_contour_apply_local(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         h->col_mask.clear();
         if (!mask.empty()) for (int c = c0; c < c0 + mc; ++c) h->col_mask.push_back(c < (int)mask.size() ? mask[c] : 1);
         h->last_node_iters.clear(); h->last_col_iters.clear();
+        mom.col0 = c0;
         rc = fh_contour_apply_panel(h, mc, dQ + (size_t)c0 * N, ritz_lambda ? ritz_lambda + c0 : nullptr,
-                                    dQproj + (size_t)c0 * N, nullptr, nullptr, ns.data(), &st);
+                                    dQproj + (size_t)c0 * N, nullptr, nullptr, ns.data(), &st, want_mom ? &mom : nullptr);
         h->col_mask = mask;
         if (rc) return rc;
         for (int e = 0; e < nodes; ++e) {
@@ -1220,6 +1235,11 @@ static int fh_contour_apply_local(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         }
     }
     h->last_node_iters = node_it; h->last_col_iters = col_it; h->last_col_m = m;
+    if (want_mom) {
+        if (h->real_projection) for (size_t i = 0; i < aq_all.size(); ++i) { aq_all[i].y = 0.0; sq_all[i].y = 0.0; }
+        if (dzAq) FH_CHECK(hipMemcpy(dzAq, aq_all.data(), aq_all.size() * sizeof(cplx), hipMemcpyHostToDevice));
+        if (dzSq) FH_CHECK(hipMemcpy(dzSq, sq_all.data(), sq_all.size() * sizeof(cplx), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 

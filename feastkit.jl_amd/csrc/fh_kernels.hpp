@@ -74,6 +74,33 @@ void fh_launch_narrow_scaled(const cplx* src, size_t src_stride, cplxf* dst, siz
 void fh_launch_widen_axpy(cplx* X, size_t x_stride, const cplxf* D, size_t d_stride, const double* r0norm,
                           int N, int ld, int nblk, int nodes, hipStream_t st);
 
+// ---- device-resident restarted GMRES(m) (fh_gmres.hip) -----------------------------------------
+struct fh_gmres_args {
+    int N; int mr;                    // restart length
+    size_t panel;                     // N * ld elements
+    cplx* V; size_t v_node_stride;    // basis panels V[node][0..mr], (mr + 1) * panel apart
+    cplx* W;                          // [node] work panel (residual at cycle start, then S v_k)
+    cplx* partial;                    // multi-dot partials [node][chunk][blk][8][ld]
+    cplx* npartial;                   // norm partials [node][blk][ld]
+    cplx* H;                          // [node*ld][(mr+1) x mr] Hessenberg columns (rotated in place)
+    cplx* hcur;                       // [node*ld][mr+1] coefficients of the running Gram-Schmidt pass
+    cplx* cs; cplx* sn;               // [node*ld][mr] Givens rotations
+    cplx* g;                          // [node*ld][mr+1] rotated right-hand side
+    cplx* y;                          // [node*ld][mr] solution of the triangular system
+    double* inv;                      // [node*ld] column scale of the next basis vector (0 = column finished)
+    double* r0norm; double* target; double* rnorm;
+    int* active; int* iters; int* status; int* kdim;   // [node*ld]
+    int* node_active;                 // [nodes]
+};
+int fh_gm_nchunk(int k);
+size_t fh_gm_partial_elems(int mr, int nblk, int nodes, int ld);
+void fh_launch_gm_orthogonalize(const fh_gmres_args& a, int ld, int k, int nblk, int nodes, hipStream_t st);
+void fh_launch_gm_start(const fh_gmres_args& a, int ld, int nblk_norm, int nodes, int first, double rtol, double atol, int m, hipStream_t st);
+void fh_launch_gm_givens(const fh_gmres_args& a, int ld, int k, int nblk, int nodes, hipStream_t st);
+void fh_launch_gm_scale_store(const fh_gmres_args& a, int ld, const cplx* src, size_t src_node_stride, int dst_index, int nblk, int nodes,
+                              hipStream_t st);
+void fh_launch_gm_finish_cycle(const fh_gmres_args& a, int ld, cplx* X, size_t x_node_stride, int kmax, int nblk, int nodes, hipStream_t st);
+
 // ---- block (panel) operations ------------------------------------------------------------
 // column-major (N x m, leading dim lds) <-> row-major panel (N x ld), zero padded
 void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
