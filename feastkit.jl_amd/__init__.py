@@ -13,7 +13,7 @@ from .contour import (feast_contour, feast_gcontour, feast_inside_gcontour, zolo
                       distribute_contour_points, balanced_contour_points)
 from . import workloads   # noqa: F401
 from .hip_backend import (feast_hip_hermitian, feast_hip_general, feast_hip_complex_symmetric,   # noqa: F401
-                          pfeast_hip_moments, seeded_subspace)   # noqa: F401
+                          pfeast_hip_moments, pfeast_hip_hermitian_moments, seeded_subspace)   # noqa: F401
 from .engine import HipEngine   # noqa: F401
 from .api import feast, feast_general   # noqa: F401
 from . import rci   # noqa: F401

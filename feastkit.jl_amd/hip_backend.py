@@ -631,3 +631,96 @@ def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None
     M = int(sum(1 for i in range(M0) if Emin <= lam[i] <= Emax))
     return FeastResult(lam[:M].copy(), q[:, :M].copy(), M, res[:M].copy(), int(FeastError.Feast_ERROR_NO_CONVERGENCE),
                        float(res[:M].max()) if M else 0.0, max_loops)
+
+
+def pfeast_hip_hermitian_moments(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
+                                 solver_restart=30, group=None, Q0=None, seed=20260515):
+    """Variant B for COMPLEX HERMITIAN input on the :hip engine -- the loop of the reference's MPI driver
+    _mpi_feast_complex_hermitian! (src/parallel/feast_mpi.jl:796-909) with the per-rank worker
+    mpi_compute_complex_hermitian_moments (:523-571) replaced by one ``contour_apply(want_moments)`` call:
+        zAq = sum_e 2 w_e Q^H Y_e,  zSq = sum_e 2 w_e z_e Q^H Y_e,  Q_proj = sum_e 2 w_e Y_e   (complex, no real part),
+    already summed over the ranks inside the C ABI (the three MPI.Allreduce of :856-858 are ONE packed reduce).
+    Then, as the reference does: Hermitian parts of the moments, eigen(Hermitian(Sq), Hermitian(Aq)) with the general
+    fallback, X = Q_proj V, inside-first reorder, the first M columns normalised, residuals with B, and ALL M0
+    columns carried to the next loop (no orthonormalisation, no compression).  Any M0 (wider than 64 columns: the
+    moment matrices are assembled block column by block column on the device).
+    Sparse input with ``solver="direct"``: there is no sparse LU on the device, the systems go through the device
+    GMRES with a purely relative 1e-13 stop.  This un-normalised iteration amplifies solver error (about 50x in the
+    first loop, 3x per further loop: measured on the reference's fixture), so with Krylov solves the outer tolerance
+    fpm[3] should not be asked below ~1e-10; dense input (batched LU) reaches 1e-12 like the reference."""
+    import scipy.sparse as _sp
+    N = A.shape[0]
+    feastdefault(fpm)
+    info = check_feast_srci_input(N, M0, Emin, Emax)
+    if info:
+        return FeastResult(np.zeros(0), np.zeros((N, 0), dtype=np.complex128), 0, np.zeros(0), info, math.inf, 0)
+    rank, world = _world(engine, group)
+    sparse = _sp.issparse(A)
+    Ac = A.astype(np.complex128)
+    Bc = B.astype(np.complex128) if B is not None else (_sp.identity(N, dtype=np.complex128, format="csr") if sparse else np.eye(N, dtype=np.complex128))
+    engine.set_problem(Ac, Bc)
+    Zne, Wne = feast_contour(Emin, Emax, fpm)
+    engine.set_contour(Zne, Wne, 2.0)                     # weight = 2 * local_Wne[e], feast_mpi.jl:548
+    engine.set_real_projection(False)
+    first, count = distribute_contour_points(len(Zne), world)[rank]
+    engine.set_node_range(first, count)
+    iterative = solver not in ("direct", "lu", "banded")
+    substituted = False
+    if solver in ("direct", "lu") and sparse:
+        # no sparse LU on the device (DESIGN.md section 7): the reference's own iterative option, restarted GMRES
+        # (solve_shifted_iterative!, feast_sparse.jl:164-203), device resident here
+        solver, iterative, substituted = "gmres", True, True
+    tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
+    if substituted:
+        # standing in for a DIRECT solve: purely relative stop at 1e-13 per column.  (The reference's iterative option
+        # stops at atol + rtol*||b|| with atol = rtol = tol; columns of this un-normalised iteration shrink to 1e-8 and
+        # an absolute 1e-12 then leaves them at 1e-4 relative -- measured: the outer residual grows 3x per loop.)
+        engine.set_solver(solver, rtol=min(tol_value, 1e-13), atol=0.0, maxit=max(solver_maxiter, 2000), restart=solver_restart)
+    else:
+        engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
+                          restart=solver_restart, cache_factors=True)
+    Q_basis = seeded_subspace(N, M0, seed, complex_values=True) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
+    dQ = engine.upload(Q_basis)
+    eps_tol = feast_tolerance(fpm)
+    lam_vec, res_vec = np.zeros(M0), np.zeros(M0)
+    epsout, info, M_found, loop_count = math.inf, 0, 0, 0
+    dX = None
+    for loop_idx in range(0, int(fpm[4]) + 1):
+        loop_count = loop_idx
+        dP, status, st, zAq, zSq = engine.contour_apply(dQ, M0, None, want_moments=True)
+        fail = int(np.max(status)) if (world > 1 or count > 0) else 0
+        if fail:                                          # _mpi_success_count(...) != size, feast_mpi.jl:849-852
+            info = int(FeastError.Feast_ERROR_LAPACK if not iterative else FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        Aq = 0.5 * (zAq + zAq.conj().T)                   # _feast_hermitian_part!
+        Sq = 0.5 * (zSq + zSq.conj().T)
+        try:
+            lam_red, v_red = _reduced_hermitian_eig(Sq, Aq)
+        except Exception:
+            info = int(FeastError.Feast_ERROR_LAPACK)
+            break
+        perm, M = _reorder_by_interval(lam_red, Emin, Emax, M0)
+        if M == 0:
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        lam_sorted = lam_red[perm]
+        V_sorted = np.asfortranarray(np.asarray(v_red, dtype=np.complex128)[:, perm])
+        # X = Q_proj V, the first M columns normalised, residual ||A x - lambda B x|| / max(|lambda|, 1) for them
+        dX, res = engine.ritz_residual(dP, M0, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+        lam_vec[:] = lam_sorted
+        res_vec[:M] = res
+        epsout = float(res.max())
+        M_found = M
+        if epsout <= eps_tol:
+            break
+        if loop_idx == int(fpm[4]):
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        dQ = dX                                           # copyto!(Q_basis, solutions): all M0 columns
+    if dX is None or M_found == 0:
+        return FeastResult(np.zeros(0), np.zeros((N, 0), dtype=np.complex128), 0, np.zeros(0),
+                           info or int(FeastError.Feast_ERROR_NO_CONVERGENCE), epsout, loop_count)
+    X = engine.download(dX, M_found)
+    order = np.argsort(lam_vec[:M_found], kind="stable")  # feast_sort!
+    return FeastResult(lam_vec[:M_found][order].copy(), X[:, order].copy(), M_found, res_vec[:M_found][order].copy(),
+                       info, epsout, loop_count)

@@ -603,6 +603,64 @@ def pfeast_moments(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, nworkers=1, see
     return FeastResult(lam[:M].copy(), q[:, :M].copy(), M, res[:M].copy(), FEAST_ERROR_NO_CONVERGENCE, eps_f, fpm4)
 
 
+def mpi_complex_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, nworkers=1, seed=20260515, Q0=None):
+    """Variant B for complex Hermitian input: _mpi_feast_complex_hermitian! (src/parallel/feast_mpi.jl:796-909) with
+    the per-rank worker mpi_compute_complex_hermitian_moments (:523-571), direct solves.  ``nworkers`` only changes
+    the order of the (exact) sums."""
+    N = A.shape[0]
+    sparse = _is_sparse(A)
+    Ac = sp.csc_matrix(A, dtype=np.complex128) if sparse else np.asarray(A, dtype=np.complex128)
+    if B is None:
+        Bc = sp.identity(N, dtype=np.complex128, format="csc") if sparse else np.eye(N, dtype=np.complex128)
+    else:
+        Bc = sp.csc_matrix(B, dtype=np.complex128) if sparse else np.asarray(B, dtype=np.complex128)
+    Zne, Wne = feast_contour(Emin, Emax, ne)
+    Q = seeded_subspace(N, M0, seed, complex_values=True) if Q0 is None else np.array(Q0, dtype=np.complex128)
+    eps_tol = feast_tolerance(fpm3)
+    lam = np.zeros(M0); res = np.zeros(M0); X = np.zeros((N, M0), dtype=np.complex128)
+    info, epsout, M_found, loop_count = FEAST_SUCCESS, math.inf, 0, 0
+    chunks = distribute_contour_points(ne, nworkers)
+    for loop_idx in range(0, fpm4 + 1):
+        loop_count = loop_idx
+        zAq = np.zeros((M0, M0), dtype=np.complex128); zSq = np.zeros_like(zAq); Q_proj = np.zeros((N, M0), dtype=np.complex128)
+        rhs = Bc @ Q
+        for chunk in chunks:
+            for e in chunk:
+                S = Zne[e] * Bc - Ac
+                Y = spla.splu(sp.csc_matrix(S)).solve(np.ascontiguousarray(rhs)) if sparse else np.linalg.solve(S, rhs)
+                weight = 2 * Wne[e]
+                a, s_ = node_moments(Q, Y, weight, Zne[e])
+                zAq += a; zSq += s_; Q_proj += weight * Y
+        Aq, Sq = hermitian_part(zAq), hermitian_part(zSq)
+        try:
+            lam_red, v_red = sla.eigh(Sq, Aq)
+        except Exception:
+            w_, v_red = sla.eig(Sq, Aq)
+            lam_red = w_.real
+        X[:, :] = Q_proj @ v_red
+        lam[:] = lam_red
+        lam, X, M, _ = reorder_by_interval(lam, X, Emin, Emax, M0)
+        if M == 0:
+            info = FEAST_ERROR_NO_CONVERGENCE
+            break
+        for j in range(M):
+            n_ = np.linalg.norm(X[:, j])
+            if n_ > 0:
+                X[:, j] /= n_
+        res[:M] = feast_residual(Ac, Bc, lam, X, M)
+        epsout = float(res[:M].max())
+        M_found = M
+        if epsout <= eps_tol:
+            break
+        if loop_idx == fpm4:
+            info = FEAST_ERROR_NO_CONVERGENCE
+            break
+        Q = X.copy()
+    if M_found > 1:
+        lam, X, res = feast_sort(lam, X, res, M_found)
+    return FeastResult(lam[:M_found].copy(), X[:, :M_found].copy(), M_found, res[:M_found].copy(), info, epsout, loop_count)
+
+
 # ---------------------------------------------------------------------------
 # Variant C: general two-sided RCI maths
 #   kernel : src/kernel/feast_kernel.jl:646-962 (feast_grci!)

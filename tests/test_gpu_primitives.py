@@ -304,6 +304,35 @@ def test_contour_apply_matches_oracle_sum(engine):
     assert np.abs(p0 + p1 - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("m", [80, 100, 129])
+def test_contour_apply_moments_wider_than_one_panel(engine, m):
+    """Variant-B moments for M0 > 64: block columns of zAq/zSq assembled panel by panel (complex Hermitian input, the
+    complex half-contour sum of src/parallel/feast_mpi.jl:564-567)."""
+    N = 300
+    rng = np.random.default_rng(4)
+    H = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    A = np.diag(np.linspace(-3, 3, N)) + 0.05 * (H + H.conj().T)
+    Zne, Wne = fo.feast_contour(-1.0, 1.0, 8)
+    engine.set_problem(A, None)
+    engine.set_contour(Zne, Wne, 2.0)
+    engine.set_real_projection(False)
+    engine.set_node_range(0, 8)
+    engine.set_solver("direct")
+    Q = rand_block(N, m, 2)
+    dP, status, stats, zAq, zSq = engine.contour_apply(engine.upload(Q), m, None, want_moments=True)
+    assert (status[:8] == 0).all()
+    ref = np.zeros((N, m), complex); rA = np.zeros((m, m), complex); rS = np.zeros((m, m), complex)
+    for z, w in zip(Zne, Wne):
+        Y = np.linalg.solve(z * np.eye(N) - A, Q)
+        ref += 2 * w * Y
+        a, s_ = fo.node_moments(Q, Y, 2 * w, z)
+        rA += a; rS += s_
+    assert np.abs(engine.download(dP, m) - ref).max() <= 1e-10 * np.abs(ref).max()
+    assert zAq.shape == (m, m)
+    assert np.abs(zAq - rA).max() <= 1e-10 * np.abs(rA).max()
+    assert np.abs(zSq - rS).max() <= 1e-10 * np.abs(rS).max()
+
+
 @pytest.mark.parametrize("N,m", [(200, 7), (1000, 32), (3000, 64)])
 def test_cocg_shifted_solve(engine, N, m):
     # complex-symmetric shifted system from real-symmetric A, B

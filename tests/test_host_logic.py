@@ -392,3 +392,30 @@ def test_feastdefault_mirrors_reference():
             fk.feastdefault(fpm)
     fpm = fk.feastinit(); fpm[2] = 24
     assert fk.feastdefault(fpm)[2] == 24            # allowed large Gauss rule
+
+
+def test_hermitian_moments_driver_equals_oracle():
+    """pfeast_hip_hermitian_moments walks _mpi_feast_complex_hermitian! (feast_mpi.jl:796-909) loop for loop: the
+    reference fixture, and a genuinely complex Hermitian pencil (where the half-contour Q_proj is not the spectral
+    projector -- the driver must still do exactly what the reference does)."""
+    k = K["mpi_complex_hermitian_diag4"]
+    A = np.diag(np.array(k["diag"], dtype=complex)); B = np.eye(4, dtype=complex)
+    fpm = fk.feastinit(); fpm[2], fpm[4] = k["fpm2"], k["fpm4"]
+    got = fk.pfeast_hip_hermitian_moments(OracleEngine(), A, B, *k["interval"], 4, fpm)
+    want = fo.mpi_complex_hermitian(A, B, *k["interval"], 4, ne=k["fpm2"], fpm4=k["fpm4"])
+    assert (got.info, got.M, got.loop) == (want.info, want.M, want.loop) == (0, 3, want.loop)
+    assert np.allclose(got.lambda_, k["expect_lambda"], atol=k["atol"]) and np.allclose(got.lambda_, want.lam, atol=1e-12)
+    n = 24
+    rng = np.random.default_rng(11)
+    H = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = np.diag(np.linspace(0.0, 6.0, n)) + 0.05 * (H + H.conj().T)
+    G = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    B = np.eye(n) + 0.02 * (G + G.conj().T)
+    ev = np.linalg.eigvalsh(np.linalg.solve(np.linalg.cholesky(B), np.linalg.solve(np.linalg.cholesky(B), A).conj().T))
+    lo, hi = 0.5 * (ev[4] + ev[5]), 0.5 * (ev[11] + ev[12])
+    for loops in (1, 3, 8):
+        fpm = fk.feastinit(); fpm[2], fpm[3], fpm[4] = 8, 11, loops
+        got = fk.pfeast_hip_hermitian_moments(OracleEngine(), A, B, lo, hi, 10, fpm)
+        want = fo.mpi_complex_hermitian(A, B, lo, hi, 10, ne=8, fpm3=11, fpm4=loops)
+        assert (got.info, got.M, got.loop) == (want.info, want.M, want.loop)
+        assert np.allclose(got.lambda_, want.lam, atol=1e-9) and abs(got.epsout - want.epsout) <= 1e-6 * max(want.epsout, 1e-12) + 1e-13

@@ -174,6 +174,18 @@ def test_mpi_complex_fixtures():
     assert r.info == 0 and r.M == 3 and np.allclose(got, want, atol=g["atol"])
 
 
+def test_mpi_complex_hermitian_moments_driver():
+    """_mpi_feast_complex_hermitian! (src/parallel/feast_mpi.jl:796-909) on the reference's own fixture
+    (test/test_parallel_backends.jl:90-113): diag(.5, 1, 1.5, 3) as a complex Hermitian pencil, one and two workers."""
+    k = K["mpi_complex_hermitian_diag4"]
+    for A, B in ((np.diag(np.array(k["diag"], dtype=complex)), np.eye(4, dtype=complex)),
+                 (sp.diags(np.array(k["diag"], dtype=complex)).tocsc(), sp.identity(4, dtype=complex, format="csc"))):
+        for nw in (1, 2):
+            r = fo.mpi_complex_hermitian(A, B, *k["interval"], 4, ne=k["fpm2"], fpm4=k["fpm4"], nworkers=nw)
+            assert r.info == 0 and r.M == 3 and np.allclose(r.lam, k["expect_lambda"], atol=k["atol"])
+            assert r.epsout <= 1e-12
+
+
 def test_distribute_contour_points():
     assert fo.distribute_contour_points(16, 8) == [[2 * i, 2 * i + 1] for i in range(8)]
     assert fo.distribute_contour_points(8, 3) == [[0, 1, 2], [3, 4, 5], [6, 7]]
