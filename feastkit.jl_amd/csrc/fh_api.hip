@@ -538,9 +538,13 @@ struct fh_solve_result {
 // sum_acc != null (COCG only): "sum mode" -- X keeps the initial guess, every step alpha p of every
 // node is added, weighted with wnode[e], to the N x ld accumulator sum_acc (zeroed by the caller), so
 // that  sum_e w_e X_e(final) = sum_e w_e X_e(initial) + sum_acc.
+// shared_src != null (sum mode, prec 64): the initial residual of every node is  f_node,c * shared_src  with
+// f = 1/(z_node - shared_lambda[c]) (device array, Ritz warm start) or 1 (shared_lambda == null: zero guess, the source
+// is RHS).  X and RHS are then never read: no warm-start panels, no residual product, no separate P = R pass.
 static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int nodes, const std::vector<cplx>& z,
                      const cplx* RHS, cplx* X, size_t stride, fh_solve_result& res, cplx* sum_acc = nullptr,
-                     const std::vector<cplx>* wnode = nullptr) {
+                     const std::vector<cplx>* wnode = nullptr, const cplx* shared_src = nullptr,
+                     const double* shared_lambda = nullptr, const cplx* dznode = nullptr) {
     if (h->kind != 2) prec = 64;          // the dense operator kernel takes complex128 panels only
     if (method != 1 || !wnode) sum_acc = nullptr;
     const int N = (int)fh_N(h);
@@ -609,7 +613,10 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     va.sum_acc = sum_acc; va.wnode = d_wnode; va.sum_scale = (sum_acc && prec == 32) ? r0_64 : nullptr; va.nodes = nodes;
 
     void* Xk = X;        // the panel the Krylov recurrences update
-    if (prec == 64) {
+    const bool shared_start = shared_src && sum_acc && method == 1 && prec == 64;
+    if (shared_start) {
+        // nothing to do here: R, P and the norms come from k_cocg_init_shared below
+    } else if (prec == 64) {
         // R = RHS - S X0, ||R||^2
         oc.prec = 64; oc.X = X; oc.x_stride = panel; oc.Y = R; oc.y_stride = panel; oc.Bvec = RHS; oc.b_stride = 0;
         oc.dot_mode = 3; oc.node_active = nullptr;
@@ -647,7 +654,13 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     }
     va.X = Xk;
     const int vprec = prec;
-    if (method == 1) {
+    if (shared_start) {
+        fh_vec_args vs = va;
+        vs.Q = shared_src; vs.lambda = shared_lambda; vs.znode = dznode;
+        fh_launch_cocg_init_shared(vs, ld, nblk_vec, nodes, h->stream);
+        fa.nblk = nblk_vec;
+        fh_launch_fin_init(fa, ld, nodes, h->stream);
+    } else if (method == 1) {
         // COCG: P = R, rho = r^T r, ||r||
         fh_launch_cocg_init(va, ld, nblk_vec, nodes, h->stream);
         fa.nblk = nblk_vec;
@@ -1039,6 +1052,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     cplx* Y = (cplx*)p;
     std::vector<int> status(nodes, 0);
     cplx* sum_acc = nullptr;
+    bool sum_shared = false;          // sum mode started from one shared residual panel: no per-node solution panels exist
 
     // destroyed on every return path (the solver branches below return early on errors)
     struct ev_guard { hipEvent_t a = nullptr, b = nullptr; ~ev_guard() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); } } evg;
@@ -1074,10 +1088,6 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
             dlam = (double*)p;
             FH_CHECK(hipMemcpy(dlam, lam.data(), ld * sizeof(double), hipMemcpyHostToDevice));
         }
-        fh_vec_args va;
-        memset(&va, 0, sizeof(va));
-        va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz;
-        fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
         fh_solve_result sr;
         // sum mode: only Q_proj is wanted (no moments), so the per-node solutions are never formed
         if (h->solver == FEASTHIP_SOLVER_COCG && !dzAq && !dzSq && !mom && h->sum_mode) {
@@ -1085,8 +1095,38 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
             sum_acc = (cplx*)p;
             FH_CHECK(hipMemsetAsync(sum_acc, 0, panel * sizeof(cplx), h->stream));
         }
+        // Shared start (sum mode, fp64 panels): the warm start Y0_e = q_c/(z_e - lambda_c) has the residual
+        // (A q_c - lambda_c B q_c)/(z_e - lambda_c) -- ONE eigen-residual panel serves every node -- and its weighted
+        // sum over the nodes is q_c * sum_e w_e/(z_e - lambda_c): neither the warm-start panels nor their residual
+        // products are ever formed.  Zero guess: the residual is RHS for every node.
+        const cplx* shared_src = nullptr;
+        sum_shared = sum_acc && h->factor_precision == 64 && !getenv("FH_NO_SHARED_START");
+        if (sum_shared) {
+            if (ritz_lambda) {
+                std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
+                for (int c = 0; c < m; ++c) cb[c] = cmake(-ritz_lambda[c], 0);
+                cplx *dca, *dcb;
+                if ((rc = fh_upload_coefs(h, "ca_rcoefA", ca, &dca))) return rc;
+                if ((rc = fh_upload_coefs(h, "ca_rcoefB", cb, &dcb))) return rc;
+                if ((rc = fh_get_buf(h, "ca_eigres", panel * sizeof(cplx), &p))) return rc;
+                fh_op_call oc;
+                oc.m = m; oc.uniform_coef = 0;
+                oc.X = Qp; oc.x_stride = 0; oc.Y = p; oc.y_stride = 0; oc.coefA = dca; oc.coefB = dcb;
+                oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+                oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+                fh_apply_operator(h, ld, oc);                    // A q - lambda B q (B = I handled by the operator kernel)
+                shared_src = (const cplx*)p;
+            } else {
+                shared_src = Rhs;
+            }
+        } else {
+            fh_vec_args va;
+            memset(&va, 0, sizeof(va));
+            va.N = N; va.node_stride = panel; va.X = Y; va.Q = Qp; va.lambda = dlam; va.znode = dz;
+            fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
+        }
         rc = fh_krylov(h, h->solver == FEASTHIP_SOLVER_COCG ? 1 : 0, h->factor_precision, ld, m, nodes, z, Rhs, Y, panel, sr,
-                       sum_acc, &w);
+                       sum_acc, &w, shared_src, dlam, dz);
         if (rc) return rc;
         status = sr.status;
         h->last_node_iters = sr.node_iters;
@@ -1132,7 +1172,18 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     cplx* dw;
     if ((rc = fh_upload_coefs(h, "ca_w", w, &dw))) return rc;
     fh_prof_begin(h, "accumulate");
-    fh_launch_accumulate(Y, panel, dw, nodes, N, ld, sum_acc, Outp, h->real_projection, h->stream);
+    if (sum_shared) {
+        cplx* drho = nullptr;
+        if (ritz_lambda) {
+            std::vector<cplx> rho(ld, cmake(0, 0));
+            for (int c = 0; c < m; ++c)
+                for (int e = 0; e < nodes; ++e) rho[c] = cadd(rho[c], cdiv(w[e], cmake(z[e].x - ritz_lambda[c], z[e].y)));
+            if ((rc = fh_upload_coefs(h, "ca_rho", rho, &drho))) return rc;
+        }
+        fh_launch_sum_finish(Qp, drho, sum_acc, Outp, N, ld, h->real_projection, h->stream);
+    } else {
+        fh_launch_accumulate(Y, panel, dw, nodes, N, ld, sum_acc, Outp, h->real_projection, h->stream);
+    }
     fh_prof_end(h);
     fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream);
 

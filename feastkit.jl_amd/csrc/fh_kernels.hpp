@@ -58,6 +58,10 @@ void fh_launch_p_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipSt
 void fh_launch_s_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+// sum-mode start from one shared source panel (a.Q = source, a.lambda/a.znode = warm-start factors or null)
+void fh_launch_cocg_init_shared(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+// OUT = [Re](SRC * rho_c + ACC)
+void fh_launch_sum_finish(const cplx* src, const cplx* rho, const cplx* acc, cplx* out, int N, int ld, int real_part, hipStream_t st);
 void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_p_sum(const fh_vec_args& a, int ld, int nodes, hipStream_t st);

@@ -644,6 +644,51 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_init(fh_vec_args a) {
     fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
 }
 
+// Sum-mode start from ONE shared source panel: R_node = f_node,c * SRC, P = R, partial1 = sum R*R, partial2 = sum |R|^2
+// with f = 1/(z_node - lambda_c) (Ritz warm start: the residual of Y0 = q/(z - lambda) is (A q - lambda B q)/(z - lambda),
+// the same vector for every node up to that scalar) or f = 1 (zero guess: R = RHS).  Replaces, per node, the warm-start
+// panel, the residual product over it and the separate P = R pass.
+template <typename CT, int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_init_shared(fh_vec_args a) {
+    const int node = blockIdx.y;
+    const size_t o = ((size_t)node * gridDim.x + blockIdx.x) * LD;
+    const size_t total = (size_t)a.N * LD;
+    const int c = threadIdx.x % LD;
+    cplx f = cmake(1, 0);
+    if (a.lambda) {
+        const cplx z = a.znode[node];
+        f = cdiv(cmake(1, 0), cmake(z.x - a.lambda[c], z.y));
+    }
+    CT* R = (CT*)a.R + (size_t)node * a.node_stride;
+    CT* P = (CT*)a.P + (size_t)node * a.node_stride;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const cplx rd = cmul(a.Q[e], f);
+        const CT r = cvt<CT>(rd);
+        R[e] = r;
+        P[e] = r;
+        d1 = cadd(d1, cmul(rd, rd));
+        d2.x += cabs2(rd);
+    }
+    __shared__ cplx red[FH_BLOCK];
+    fh_block_reduce_cols<LD>(d1, red, a.partial1 + o);
+    fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
+}
+
+// Q_proj of a sum-mode sweep: OUT = [Re] ( SRC * rho_c + ACC ), rho_c = sum_e w_e / (z_e - lambda_c) -- the weighted sum of
+// the warm starts in closed form (no per-node panels) plus the accumulated Krylov corrections.  rho == null: OUT = [Re] ACC.
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_sum_finish(const cplx* __restrict__ src, const cplx* __restrict__ rho,
+                                                          const cplx* __restrict__ acc, cplx* __restrict__ out, size_t total, int real_part) {
+    const cplx rc = rho ? rho[threadIdx.x % LD] : cmake(0, 0);
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx v = acc[e];
+        if (rho) cfma(v, rc, src[e]);
+        if (real_part) v.y = 0.0;
+        out[e] = v;
+    }
+}
+
 template <typename CT, int LD>
 __global__ __launch_bounds__(FH_BLOCK) void k_cocg_update(fh_vec_args a) {
     // X += alpha P ; R -= alpha Q (Q stored in V) ; partial1 = sum R*R, partial2 = sum |R|^2
@@ -789,6 +834,16 @@ void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipS
 }
 void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
     FH_DISPATCH_VEC(a.prec, ld, k_cocg_init, dim3(nblk, nodes), st, a);
+}
+void fh_launch_cocg_init_shared(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    FH_DISPATCH_VEC(a.prec, ld, k_cocg_init_shared, dim3(nblk, nodes), st, a);
+}
+void fh_launch_sum_finish(const cplx* src, const cplx* rho, const cplx* acc, cplx* out, int N, int ld, int real_part, hipStream_t st) {
+    const size_t total = (size_t)N * ld;
+    const int nblk = (int)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048);
+    if (ld == 16) hipLaunchKernelGGL((k_sum_finish<16>), dim3(nblk), dim3(FH_BLOCK), 0, st, src, rho, acc, out, total, real_part);
+    else if (ld == 32) hipLaunchKernelGGL((k_sum_finish<32>), dim3(nblk), dim3(FH_BLOCK), 0, st, src, rho, acc, out, total, real_part);
+    else hipLaunchKernelGGL((k_sum_finish<64>), dim3(nblk), dim3(FH_BLOCK), 0, st, src, rho, acc, out, total, real_part);
 }
 void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
     FH_DISPATCH_VEC(a.prec, ld, k_cocg_update, dim3(nblk, nodes), st, a);
