@@ -332,8 +332,8 @@ def main():
 
     # per-node Krylov iterations of the last step, summed over its refinement loops (this rank's nodes)
     node_its = {}
-    for per_loop in res.stats.get("node_iterations", []):
-        for g, v in zip(res.stats.get("local_nodes", []), per_loop):
+    for nodes_l, per_loop in zip(res.stats.get("node_lists", []), res.stats.get("node_iterations", [])):
+        for g, v in zip(nodes_l, per_loop):
             node_its[int(g)] = node_its.get(int(g), 0) + int(v)
     nr, rk, transport = eng.comm_size, eng.comm_rank, {0: "none", 1: "rccl", 2: "shm (ranks share a device)"}
     tr = eng.comm_transport() if hasattr(eng, "comm_transport") else 0

@@ -10,7 +10,7 @@ from .types import (FeastError, FeastRCIJob, FeastResult, FeastGeneralResult,   
                     FeastHipError, FEAST_UNINITIALIZED)
 from .parameters import feastinit, feastdefault, feast_tolerance, check_feast_srci_input   # noqa: F401
 from .contour import (feast_contour, feast_gcontour, feast_inside_gcontour, zolotarev_point,   # noqa: F401
-                      distribute_contour_points, balanced_contour_points)
+                      distribute_contour_points, balanced_contour_points, cost_balanced_contour_points)
 from . import workloads   # noqa: F401
 from .hip_backend import (feast_hip_hermitian, feast_hip_general, feast_hip_complex_symmetric,   # noqa: F401
                           pfeast_hip_moments, pfeast_hip_hermitian_moments, seeded_subspace)   # noqa: F401

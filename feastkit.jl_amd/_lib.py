@@ -63,6 +63,7 @@ SYMBOLS = {
     "feasthip_shifted_solve_dev": (_i, [_vp, _d, _d, _i64, _vp, _vp, _ps]),
     "feasthip_last_node_iterations": (_i, [_vp, _vp, _i]),
     "feasthip_last_column_iterations": (_i, [_vp, _vp, _i]),
+    "feasthip_last_global_node_iterations": (_i, [_vp, _vp, _i]),
     "feasthip_profile_enable": (_i, [_vp, _i]),
     "feasthip_profile_reset": (_i, [_vp]),
     "feasthip_profile_get": (_i, [_vp, C.c_char_p, _pd, _pi64]),

@@ -135,3 +135,24 @@ def balanced_contour_points(ne, nw):
         r, k = divmod(e, nw)
         out[k if r % 2 == 0 else nw - 1 - k].append(e)
     return out
+
+
+def cost_balanced_contour_points(costs, nw):
+    """Node lists from measured per-node costs (Krylov iterations of the previous sweep): longest-processing-time
+    greedy -- nodes by decreasing cost (ties: lower index first) onto the currently lightest worker (ties: lower
+    worker first).  Deterministic, so every rank derives the same lists from the same reduced counts.  Each worker
+    keeps at least one node while there are enough nodes."""
+    ne = len(costs)
+    order = sorted(range(ne), key=lambda e: (-float(costs[e]), e))
+    load = [0.0] * nw
+    out = [[] for _ in range(nw)]
+    for e in order:
+        empty = [k for k in range(nw) if not out[k]]
+        remaining = ne - sum(len(o) for o in out)
+        if empty and remaining <= len(empty):
+            k = empty[0]
+        else:
+            k = min(range(nw), key=lambda q: (load[q], q))
+        out[k].append(e)
+        load[k] += float(costs[e]) + 1.0          # +1: a node costs something even when it converged at once
+    return [sorted(o) for o in out]

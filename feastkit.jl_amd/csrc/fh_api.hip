@@ -1337,7 +1337,7 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     const int local_rc = rc;
     const size_t nq = (size_t)N * m * (h->real_projection ? 1 : 2);
     const size_t nm = (size_t)m * m * 2;
-    const size_t total = nq + (dzAq ? nm : 0) + (dzSq ? nm : 0) + 2 * (size_t)ne + 1;
+    const size_t total = nq + (dzAq ? nm : 0) + (dzSq ? nm : 0) + 3 * (size_t)ne + 1;
     void* p;
     if ((rc = fh_get_buf(h, "comm_pack", total * sizeof(double), &p))) return rc;
     double* pack = (double*)p;
@@ -1346,13 +1346,15 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     size_t off = nq;
     if (dzAq) { FH_CHECK(hipMemcpyAsync(pack + off, dzAq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
     if (dzSq) { FH_CHECK(hipMemcpyAsync(pack + off, dzSq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
-    std::vector<double> flags(2 * (size_t)ne + 1, 0.0);
+    // tail of the packed buffer: [no-convergence flags | singular flags | Krylov iterations per contour node | rank failed]
+    std::vector<double> flags(3 * (size_t)ne + 1, 0.0);
     for (int e = 0; e < nodes; ++e) {
         const int g = h->node_ids[e];
         if (ns[e] == FEASTHIP_ERROR_LAPACK) flags[ne + g] = 1.0;
         else if (ns[e] != 0) flags[g] = 1.0;
+        if (c1 > c0 && e < (int)h->last_node_iters.size()) flags[2 * (size_t)ne + g] = (double)h->last_node_iters[e];
     }
-    flags[2 * (size_t)ne] = local_rc ? 1.0 : 0.0;
+    flags[3 * (size_t)ne] = local_rc ? 1.0 : 0.0;
     FH_CHECK(hipMemcpyAsync(pack + off, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (local_rc) {
         // our own payload may be garbage: contribute zeros so that the peers' sums stay finite
@@ -1372,8 +1374,10 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     if (node_status)
         for (int g = 0; g < ne; ++g)
             node_status[g] = flags[ne + g] > 0.0 ? (int)FEASTHIP_ERROR_LAPACK : (flags[g] > 0.0 ? (int)FEASTHIP_ERROR_NO_CONVERGENCE : 0);
+    h->global_node_iters.assign(ne, 0);
+    for (int g = 0; g < ne; ++g) h->global_node_iters[g] = (int)(flags[2 * (size_t)ne + g] + 0.5);
     if (local_rc) return local_rc;
-    if (flags[2 * (size_t)ne] > 0.0) { h->last_error = "contour_apply: the sweep failed on another rank"; return FEASTHIP_ERROR_INTERNAL; }
+    if (flags[3 * (size_t)ne] > 0.0) { h->last_error = "contour_apply: the sweep failed on another rank"; return FEASTHIP_ERROR_INTERNAL; }
     return 0;
 }
 
@@ -2276,6 +2280,12 @@ extern "C" int feasthip_shifted_solve(feasthip_handle h, double z_re, double z_i
 extern "C" int feasthip_last_node_iterations(feasthip_handle h, int* out, int n) {
     if (!h || !out) return FEASTHIP_ERROR_INTERNAL;
     for (int e = 0; e < n; ++e) out[e] = e < (int)h->last_node_iters.size() ? h->last_node_iters[e] : 0;
+    return 0;
+}
+
+extern "C" int feasthip_last_global_node_iterations(feasthip_handle h, int* out, int n) {
+    if (!h || !out) return FEASTHIP_ERROR_INTERNAL;
+    for (int e = 0; e < n; ++e) out[e] = e < (int)h->global_node_iters.size() ? h->global_node_iters[e] : 0;
     return 0;
 }
 

@@ -142,6 +142,7 @@ struct feasthip_ctx {
     std::vector<int> last_col_iters;    // [local node][m] iterations per column of the last sweep
     int last_col_m = 0;
     std::vector<int> last_node_iters;   // per local node: max column iterations of the last sweep
+    std::vector<int> global_node_iters; // per CONTOUR node, summed over the ranks by the packed reduce of the last sweep
 
     // workspace (grown lazily)
     std::map<std::string, std::pair<void*, size_t>> bufs;

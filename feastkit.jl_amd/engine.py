@@ -343,6 +343,12 @@ class HipEngine:
         self._chk(self.lib.feasthip_last_node_iterations(self.h, _np_ptr(out), int(n)))
         return out[:n]
 
+    def last_global_node_iterations(self):
+        """Per contour node, summed over the ranks (multi-rank sweeps only): the cost signal for node re-balancing."""
+        out = np.zeros(max(1, self.ne), dtype=np.int32)
+        self._chk(self.lib.feasthip_last_global_node_iterations(self.h, _np_ptr(out), int(self.ne)))
+        return out[:self.ne]
+
     def last_column_iterations(self, nodes, m):
         out = np.zeros(max(1, nodes * m), dtype=np.int32)
         self._chk(self.lib.feasthip_last_column_iterations(self.h, _np_ptr(out), int(nodes * m)))

@@ -29,7 +29,7 @@ import time
 import numpy as np
 import scipy.linalg as sla
 
-from .contour import balanced_contour_points, distribute_contour_points, feast_contour, feast_gcontour, feast_inside_gcontour
+from .contour import balanced_contour_points, cost_balanced_contour_points, distribute_contour_points, feast_contour, feast_gcontour, feast_inside_gcontour
 from .parameters import check_feast_srci_input, feast_tolerance, feastdefault
 from .types import FeastError, FeastResult
 
@@ -236,7 +236,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     eps_hist, inner_cap = [], int(solver_maxiter)
     dX = None
     stats = {"setup_seconds": t_setup, "krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0,
-             "solve_seconds": 0.0, "loops": [], "node_iterations": [], "local_nodes": [int(v) for v in local_nodes], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
+             "solve_seconds": 0.0, "loops": [], "node_iterations": [], "node_lists": [], "local_nodes": [int(v) for v in local_nodes], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
                                                                    "project": 0.0, "eig": 0.0, "ritz": 0.0}}
     ph = stats["phase_seconds"]
     tick = time.perf_counter
@@ -267,7 +267,17 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         stats["solve_seconds"] += st.get("seconds_solve", 0.0)
         if hasattr(engine, "last_node_iterations"):
             stats["node_iterations"].append([int(v) for v in engine.last_node_iterations(count)])
+            stats["node_lists"].append([int(v) for v in local_nodes])
         local_fail = int(np.max(status)) if (world > 1 or count > 0) else 0
+        if (node_assignment == "balanced" and node_groups > 1 and iterative and hasattr(engine, "last_global_node_iterations")
+                and loop_idx >= 1):
+            # re-balance the node groups from the iteration counts the sweep just measured (they arrived in the tail of the
+            # packed all-reduce and are identical on every rank): the slow near-axis nodes no longer share a group by accident
+            nodes_here = cost_balanced_contour_points(engine.last_global_node_iterations(), node_groups)[node_rank]
+            if list(nodes_here) != list(local_nodes):
+                engine.set_node_list(nodes_here)
+                count, local_nodes = len(nodes_here), list(nodes_here)
+                stats["local_nodes"] = [int(v) for v in local_nodes]
         if local_fail == 8 or (local_fail == 5 and not warm_start):
             # direct: singular shift -> info 8 (src/dense/feast_dense.jl:199-203);
             # reference GMRES failure -> info 5 (src/dense/feast_dense.jl:221-225)

@@ -269,6 +269,11 @@ int  feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double z_im, int
  * "lu_panel", "lu_gemm", "trsm", "gram", "ortho".  Used by bench.py's roofline object.     */
 /* Per local node: iterations of the slowest column in the last iterative sweep. */
 int  feasthip_last_node_iterations(feasthip_handle h, int* out, int n);
+/* With a communicator: Krylov iterations of the last sweep per CONTOUR node (ne entries), summed over the ranks that
+ * worked on the node (they travel in the tail of the packed all-reduce).  Identical on every rank, so hosts can
+ * re-balance the node lists between refinement loops deterministically (nodes next to the real axis need 10x the
+ * iterations of the others).                                                                              */
+int  feasthip_last_global_node_iterations(feasthip_handle h, int* out, int n);
 /* [local node][m] iterations per column of the last iterative sweep (row-major, n entries). */
 int  feasthip_last_column_iterations(feasthip_handle h, int* out, int n);
 int  feasthip_profile_enable(feasthip_handle h, int enable);

@@ -188,3 +188,58 @@ def test_cfg3_full_size_ranks_on_one_card(tmp_path, world, aspect, cap):
     res = [np.load(tmp_path / f"c{r}.npy") for r in range(world)]
     assert all(np.array_equal(res[0], x) for x in res[1:])
     assert int(res[0][1]) == 44
+
+
+REBAL = r'''
+import os, sys, time, json, faulthandler
+faulthandler.dump_traceback_later(300, exit=True)
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np
+import feast_oracle as fo, feastkit_jl_amd as fk
+rank, world, out = int(sys.argv[1]), int(sys.argv[2]), r"{out}"
+eng = fk.HipEngine(0)
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    open(uidf + ".tmp", "wb").write(eng.comm_unique_id()); os.rename(uidf + ".tmp", uidf)
+else:
+    t0 = time.time()
+    while not os.path.exists(uidf):
+        time.sleep(0.01); assert time.time() - t0 < 120
+eng.comm_init(world, rank, open(uidf, "rb").read(), "shm")
+A, B, lam = fo.cfg3_problem(16, 12, 10)
+fpm = fk.feastinit(); fpm[2], fpm[4], fpm[18] = 16, 40, 1500
+r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 48, fpm, solver="cocg", warm_start=True, inner_rtol=3e-2, solver_maxiter=60,
+                           node_assignment="balanced", column_groups=1, real_projection=True)
+json.dump({{"info": r.info, "M": r.M, "eps": r.epsout, "lam": list(np.sort(r.lambda_)), "lists": r.stats["node_lists"],
+           "its": r.stats["node_iterations"]}}, open(os.path.join(out, "b%d.json" % rank), "w"))
+eng.barrier(); eng.comm_destroy(); eng.close()
+'''
+
+
+def test_node_groups_rebalance_between_loops(engine, tmp_path):
+    """Two node groups on one card: after loop 1 the groups are rebuilt from the iteration counts that travelled in the
+    packed reduce (identical on both ranks).  Every loop's two lists partition the 16 nodes, the lists do change, and the
+    result is the single-rank result."""
+    import json
+    script = tmp_path / "rebal.py"
+    script.write_text(REBAL.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FEASTHIP_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    b = [json.load(open(tmp_path / f"b{r}.json")) for r in range(2)]
+    A, B, lam = fo.cfg3_problem(16, 12, 10)
+    inside = lam[(lam >= 0) & (lam <= 0.42)]
+    for x in b:
+        assert x["info"] == 0 and x["M"] == len(inside) and x["eps"] <= 1e-12
+        assert np.allclose(x["lam"], inside, atol=1e-10)
+    assert b[0]["lam"] == b[1]["lam"]
+    assert len(b[0]["lists"]) == len(b[1]["lists"]) >= 3
+    for l0, l1 in zip(b[0]["lists"], b[1]["lists"]):
+        assert sorted(l0 + l1) == list(range(16))
+    assert b[0]["lists"][0] == fk.balanced_contour_points(16, 2)[0]            # loops 0 and 1: the a-priori snake
+    assert any(l != b[0]["lists"][0] for l in b[0]["lists"][2:])                # later loops: measured costs
+    # the re-balanced groups carry comparable work
+    last0, last1 = sum(b[0]["its"][-1]), sum(b[1]["its"][-1])
+    assert abs(last0 - last1) <= 0.35 * (last0 + last1)

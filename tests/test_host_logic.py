@@ -419,3 +419,18 @@ def test_hermitian_moments_driver_equals_oracle():
         want = fo.mpi_complex_hermitian(A, B, lo, hi, 10, ne=8, fpm3=11, fpm4=loops)
         assert (got.info, got.M, got.loop) == (want.info, want.M, want.loop)
         assert np.allclose(got.lambda_, want.lam, atol=1e-9) and abs(got.epsout - want.epsout) <= 1e-6 * max(want.epsout, 1e-12) + 1e-13
+
+
+def test_cost_balanced_contour_points():
+    """Node lists from measured iteration counts: deterministic LPT, every node exactly once, heavy nodes apart."""
+    costs = [170, 128, 91, 76, 59, 52, 49, 49, 49, 49, 56, 59, 78, 101, 165, 399]      # cfg 3 on the bench's contour
+    groups = fk.cost_balanced_contour_points(costs, 2)
+    assert sorted(groups[0] + groups[1]) == list(range(16))
+    loads = [sum(costs[e] for e in g) for g in groups]
+    assert abs(loads[0] - loads[1]) <= 0.05 * sum(costs)
+    assert (15 in groups[0]) != (0 in groups[0]) or abs(loads[0] - loads[1]) < 60      # the two slowest nodes are not stacked
+    assert fk.cost_balanced_contour_points(costs, 2) == groups                          # deterministic
+    g3 = fk.cost_balanced_contour_points([5, 5, 5], 5)
+    assert sorted(sum(g3, [])) == [0, 1, 2] and sum(1 for g in g3 if g) == 3
+    g1 = fk.cost_balanced_contour_points([0, 0, 0, 0], 2)
+    assert sorted(sum(g1, [])) == [0, 1, 2, 3] and all(len(g) == 2 for g in g1)
