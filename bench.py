@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the cfg 2 / cfg 5 dense measurements after the headline")
     ap.add_argument("--no-default-contour", action="store_true", help="skip the secondary run on the reference's default contour")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline solve (profiling passes): no mixed-precision, "
+                    "default-contour, CPU or dense measurements")
     ap.add_argument("--reduced-solver", default="host", choices=["host", "device"])
     args = ap.parse_args()
 
@@ -232,6 +234,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: no hostname resolution needed
         dist.init_process_group("gloo")            # control plane only: carries RCCL's unique id
         eng.comm_init_from_group(None)             # data plane: RCCL inside the C ABI (shared-device transport if ranks share a GPU)
     if world != args.gpus and rank == 0:
@@ -358,7 +362,7 @@ def main():
         "solve_seconds_last_step": round(float(res.stats.get("solve_seconds", 0.0)), 4),
         "roofline": cands[0] if cands else None, "roofline_other": cands[1:], "kernel_classes": classes,
     }
-    if rk == 0 and nr == 1:
+    if rk == 0 and nr == 1 and not args.headline_only:
         # secondary measurements, none of them the headline value
         fence()
         step(32)

@@ -1469,6 +1469,59 @@ static double fh_pivoted_cholesky_ratio(std::vector<cplx> G, int m, int ld) {
     return dmax > 0.0 ? dmin / dmax : 0.0;
 }
 
+// Real twins of the two routines for a Gram matrix without imaginary parts (real projection of real-symmetric input:
+// Q_proj is real): the same arithmetic on a quarter of the flops -- the host's share of the orthonormalisation was
+// most of the 0.56 ms the step took per refinement loop on cfg 3.
+static double fh_pivoted_cholesky_ratio_real(std::vector<double> G, int m) {
+    double dmax = 0.0, dmin = 0.0;
+    auto at = [&](int i, int j) -> double& { return G[(size_t)j * m + i]; };
+    for (int k = 0; k < m; ++k) {
+        int p = k;
+        for (int j = k + 1; j < m; ++j) if (at(j, j) > at(p, p)) p = j;
+        if (p != k) {
+            for (int j = 0; j < m; ++j) std::swap(at(k, j), at(p, j));
+            for (int i = 0; i < m; ++i) std::swap(at(i, k), at(i, p));
+        }
+        const double d = at(k, k);
+        if (k == 0) dmax = d;
+        if (!(d > 0.0) || !std::isfinite(d)) return 0.0;
+        dmin = d;
+        const double r = std::sqrt(d);
+        for (int i = k + 1; i < m; ++i) at(i, k) /= r;
+        for (int j = k + 1; j < m; ++j) {
+            const double ajk = at(j, k);
+            for (int i = j; i < m; ++i) { const double v = at(i, j) - at(i, k) * ajk; at(i, j) = v; at(j, i) = v; }
+        }
+    }
+    return dmax > 0.0 ? dmin / dmax : 0.0;
+}
+static bool fh_chol_upper_inverse_real(const std::vector<double>& G, int m, int ld, std::vector<cplx>& Rinv) {
+    std::vector<double> R((size_t)m * m, 0.0), X((size_t)m * m, 0.0);
+    auto r = [&](int i, int j) -> double& { return R[(size_t)j * m + i]; };
+    for (int j = 0; j < m; ++j)
+        for (int i = 0; i <= j; ++i) {
+            double sum = G[(size_t)j * m + i];
+            for (int k = 0; k < i; ++k) sum -= r(k, i) * r(k, j);
+            if (i == j) {
+                if (!(sum > 0.0) || !std::isfinite(sum)) return false;
+                r(i, i) = std::sqrt(sum);
+            } else {
+                r(i, j) = sum / r(i, i);
+            }
+        }
+    Rinv.assign((size_t)ld * ld, cmake(0, 0));
+    for (int j = 0; j < m; ++j) {
+        X[(size_t)j * m + j] = 1.0 / r(j, j);
+        for (int i = j - 1; i >= 0; --i) {
+            double sum = 0.0;
+            for (int k = i + 1; k <= j; ++k) sum += r(i, k) * X[(size_t)j * m + k];
+            X[(size_t)j * m + i] = -sum / r(i, i);
+        }
+        for (int i = 0; i <= j; ++i) Rinv[(size_t)j * ld + i] = cmake(X[(size_t)j * m + i], 0);
+    }
+    return true;
+}
+
 // Rinv (ld x ld, column-major, zero padded) with G = R^H R, R upper triangular; false if not PD
 static bool fh_chol_upper_inverse(const std::vector<cplx>& G, int m, int ld, std::vector<cplx>& Rinv) {
     std::vector<cplx> R((size_t)m * m, cmake(0, 0));
@@ -1538,6 +1591,7 @@ static int fh_ortho_panel(feasthip_ctx* h, int m, int ld, cplx* X, cplx* Out, do
             FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
             FH_CHECK(hipStreamSynchronize(h->stream));
             std::vector<double> dcol;
+            double dmin_eq = 1.0, dmax_eq = 1.0;
             if (pass == 0) {
                 // Equilibrate: G = D G' D with D = diag(column norms).  Columns of very different
                 // length (e.g. guard columns scaled by a small filter value) make G ill-conditioned
@@ -1558,10 +1612,22 @@ static int fh_ortho_panel(feasthip_ctx* h, int m, int ld, cplx* X, cplx* Out, do
                         cplx& g = Gh[(size_t)j * ld + i];
                         g = cscale(g, 1.0 / (dcol[i] * dcol[j]));
                     }
-                const double ratio = fh_pivoted_cholesky_ratio(Gh, m, ld);
-                if (!(ratio > 1e-10) || !((dmin / dmax) * std::sqrt(ratio) > 1e3 * rank_tol)) { ok = false; break; }
+                dmin_eq = dmin; dmax_eq = dmax;
             }
-            if (!fh_chol_upper_inverse(Gh, m, ld, Rinv)) { ok = false; break; }
+            // a Gram matrix without imaginary parts (real Q_proj) takes the real routines
+            bool is_real = true;
+            for (int j = 0; j < m && is_real; ++j)
+                for (int i = 0; i < m; ++i) if (Gh[(size_t)j * ld + i].y != 0.0) { is_real = false; break; }
+            std::vector<double> Gr;
+            if (is_real) {
+                Gr.resize((size_t)m * m);
+                for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) Gr[(size_t)j * m + i] = Gh[(size_t)j * ld + i].x;
+            }
+            if (pass == 0) {
+                const double ratio = is_real ? fh_pivoted_cholesky_ratio_real(Gr, m) : fh_pivoted_cholesky_ratio(Gh, m, ld);
+                if (!(ratio > 1e-10) || !((dmin_eq / dmax_eq) * std::sqrt(ratio) > 1e3 * rank_tol)) { ok = false; break; }
+            }
+            if (!(is_real ? fh_chol_upper_inverse_real(Gr, m, ld, Rinv) : fh_chol_upper_inverse(Gh, m, ld, Rinv))) { ok = false; break; }
             if (pass == 0)       // R = R' D  =>  R^-1 = D^-1 R'^-1: scale row i by 1/d_i
                 for (int j = 0; j < m; ++j)
                     for (int i = 0; i < m; ++i) Rinv[(size_t)j * ld + i] = cscale(Rinv[(size_t)j * ld + i], 1.0 / dcol[i]);

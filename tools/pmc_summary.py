@@ -2,7 +2,7 @@
 pass of the same command) into per-kernel HBM bytes per launch.
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts half of a wide coalesced
 read -> bytes = 2 * FETCH_KB * 1024; WRITE_SIZE is exact -> bytes = WRITE_KB * 1024.
-Usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<command>"
+Usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<command>" [kernel_source_hash]
 """
 import collections
 import csv
@@ -26,6 +26,7 @@ def per_kernel(path, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"command": sys.argv[4] if len(sys.argv) > 4 else "",
+       "kernel_source_hash": sys.argv[5] if len(sys.argv) > 5 else "",      # bench.py quotes the traffic only for matching kernel sources
        "correction": "gfx950: FETCH_SIZE counts half of a wide coalesced read (MI355X_MICROARCH.md, HBM): bytes = 2*FETCH_KB*1024; "
                      "WRITE_SIZE exact: bytes = WRITE_KB*1024",
        "kernels": {}}
