@@ -423,11 +423,15 @@ __device__ __forceinline__ cplx fh_sum_partials(const cplx* partial, int node, i
     cplx s0 = cmake(0, 0), s1 = cmake(0, 0);
     const cplx* p = partial + (size_t)node * nblk * LD + c;
     int b = g;
-    for (; b + 3 * G < nblk; b += 4 * G) {          // four independent loads in flight per thread
-        const cplx v0 = p[(size_t)b * LD], v1 = p[(size_t)(b + G) * LD], v2 = p[(size_t)(b + 2 * G) * LD],
-                   v3 = p[(size_t)(b + 3 * G) * LD];
-        s0 = cadd(s0, cadd(v0, v1));
-        s1 = cadd(s1, cadd(v2, v3));
+    // The partial rows were written by other XCDs: every load is a trip to HBM / the Infinity Cache (1-2 us).  Eight
+    // independent loads in flight per thread, summed in a fixed order (deterministic): the kernel is a latency chain,
+    // its length is the number of such batches (2 for the 256 rows of a 16-node sweep), not the bytes.
+    for (; b + 7 * G < nblk; b += 8 * G) {
+        cplx v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q * G) * LD];
+        s0 = cadd(s0, cadd(cadd(v[0], v[1]), cadd(v[2], v[3])));
+        s1 = cadd(s1, cadd(cadd(v[4], v[5]), cadd(v[6], v[7])));
     }
     for (; b < nblk; b += G) s0 = cadd(s0, p[(size_t)b * LD]);
     red[t] = cadd(s0, s1);
@@ -452,11 +456,12 @@ __device__ __forceinline__ void fh_sum_partials2(const cplx* partial1, const cpl
     const cplx* p = partial1 + (size_t)node * nblk * LD + c;
     const cplx* q = partial2 + (size_t)node * nblk * LD + c;
     int b = g;
-    for (; b + G < nblk; b += 2 * G) {
-        const cplx u0 = p[(size_t)b * LD], u1 = p[(size_t)(b + G) * LD];
-        const cplx w0 = q[(size_t)b * LD], w1 = q[(size_t)(b + G) * LD];
-        a0 = cadd(a0, u0); a1 = cadd(a1, u1);
-        b0 = cadd(b0, w0); b1 = cadd(b1, w1);
+    for (; b + 3 * G < nblk; b += 4 * G) {       // 4 + 4 independent loads in flight (see fh_sum_partials)
+        cplx u[4], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { u[k] = p[(size_t)(b + k * G) * LD]; w[k] = q[(size_t)(b + k * G) * LD]; }
+        a0 = cadd(a0, cadd(u[0], u[1])); a1 = cadd(a1, cadd(u[2], u[3]));
+        b0 = cadd(b0, cadd(w[0], w[1])); b1 = cadd(b1, cadd(w[2], w[3]));
     }
     for (; b < nblk; b += G) { a0 = cadd(a0, p[(size_t)b * LD]); b0 = cadd(b0, q[(size_t)b * LD]); }
     red[t] = cadd(a0, a1);
