@@ -37,12 +37,12 @@ EMIN, EMAX, M0, NE = 0.0, 0.1775, 64, 16
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: PMC traffic files record it, stale ones are not quoted."""
+    """sha256 over the sources of the Krylov kernels the roofline object is about (fh_sparse.hip and the headers it
+    includes): PMC traffic files record it, a file whose kernels have changed since is not quoted."""
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "feastkit.jl_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
-            hsh.update(open(os.path.join(d, name), "rb").read())
+    for name in ("fh_sparse.hip", "fh_common.hpp", "fh_kernels.hpp"):
+        hsh.update(open(os.path.join(d, name), "rb").read())
     return hsh.hexdigest()[:16]
 
 

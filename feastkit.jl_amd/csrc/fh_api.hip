@@ -743,6 +743,14 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                     h->last_error = std::string("device queue failed while iterating: ") + hipGetErrorString(q);
                     return FEASTHIP_ERROR_INTERNAL;
                 }
+                // a wedged kernel keeps answering "not ready": overall deadline, generous against the slowest
+                // measured iteration (2 ms with 16 nodes x 64 columns at N = 50 000), scaled by the problem size
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop0).count();
+                const double budget = 30.0 + 0.05 * (double)h->maxit * (1.0 + (double)N * nodes / 8.0e5);
+                if (waited > budget) {
+                    h->last_error = "device did not make progress on the Krylov iterations within the deadline (" + std::to_string((int)budget) + " s)";
+                    return FEASTHIP_ERROR_INTERNAL;
+                }
             }
         }
     }
