@@ -243,3 +243,51 @@ def test_node_groups_rebalance_between_loops(engine, tmp_path):
     # the re-balanced groups carry comparable work
     last0, last1 = sum(b[0]["its"][-1]), sum(b[1]["its"][-1])
     assert abs(last0 - last1) <= 0.35 * (last0 + last1)
+
+
+CFG5 = r'''
+import os, sys, time, faulthandler
+faulthandler.dump_traceback_later(300, exit=True)
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np
+import feastkit_jl_amd as fk
+rank, world, out = int(sys.argv[1]), int(sys.argv[2]), r"{out}"
+eng = fk.HipEngine(0)
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    open(uidf + ".tmp", "wb").write(eng.comm_unique_id()); os.rename(uidf + ".tmp", uidf)
+else:
+    t0 = time.time()
+    while not os.path.exists(uidf):
+        time.sleep(0.01); assert time.time() - t0 < 120
+eng.comm_init(world, rank, open(uidf, "rb").read(), "shm")
+A, delta = fk.workloads.disc_spectrum_general(512)
+inside = delta[np.abs(delta) <= 2.0]
+key = lambda x: (round(x.real, 7), round(x.imag, 7))
+res = []
+for prec in (64, 32):
+    fpm = fk.feastinit(); fpm[8] = 24; fpm[4] = 20
+    r = fk.feast_hip_general(eng, A, None, 0.0, 2.0, 48, fpm, inner_precision=prec)
+    assert r.info == 0 and r.M == len(inside), (r.info, r.M, len(inside))
+    err = np.abs(np.array(sorted(r.lambda_, key=key)) - np.array(sorted(inside, key=key))).max()
+    hres = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
+    assert err < 1e-10 and hres.max() < 1e-10, (err, hres.max())
+    res += [r.M, r.loop] + [v for x in sorted(r.lambda_, key=key) for v in (x.real, x.imag)]
+np.save(os.path.join(out, "g%d.npy" % rank), np.array(res))
+eng.barrier(); eng.comm_destroy(); eng.close()
+'''
+
+
+def test_cfg5_split_four_ranks_general_lu(tmp_path):
+    """BASELINE cfg 5's split -- 24 full-contour nodes over 4 ranks, 6 per rank, batched complex LU (complex128 and
+    complex64 + fp64 refinement), M0 = 48 -- at N = 512 on one card: every rank returns the eigenvalues inside the
+    circle (known by construction) to 1e-10, identical on all ranks."""
+    script = tmp_path / "cfg5.py"
+    script.write_text(CFG5.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FEASTHIP_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(4)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    g = [np.load(tmp_path / f"g{r}.npy") for r in range(4)]
+    assert all(np.array_equal(g[0], x) for x in g[1:])
