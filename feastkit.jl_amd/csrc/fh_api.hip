@@ -163,6 +163,7 @@ static void fh_free_problem(feasthip_ctx* h) {
     if (h->csr.col) hipFree(h->csr.col);
     if (h->csr.aval) hipFree(h->csr.aval);
     if (h->csr.bval) hipFree(h->csr.bval);
+    if (h->csr.perm) hipFree(h->csr.perm);
     h->csr = fh_csr();
     if (h->dense.A) hipFree(h->dense.A);
     if (h->dense.B) hipFree(h->dense.B);
@@ -265,6 +266,77 @@ static inline cplx vzero(cplx) { return cmake(0, 0); }
 static inline double vadd(double a, double b) { return a + b; }
 static inline cplx vadd(cplx a, cplx b) { return cadd(a, b); }
 
+// ---------------------------------------------------------------------------------------
+// Row blocks for the LDS-window SpMM (fh_sparse.hip).  The hot SpMM stages the X rows a block of FH_SPMM_R consecutive
+// matrix rows touches into LDS; that only pays when most of a block's column indices fall inside the block itself.
+// Ingest therefore renumbers the unknowns: greedy graph growing on the union pattern (the GGGP seed/grow step of
+// multilevel partitioners: always add the frontier vertex with the most neighbours already in the block), blocks filled to
+// exactly FH_SPMM_R rows, the next block seeded next to the previous ones so that neighbouring blocks get neighbouring
+// numbers.  The permutation never leaves the library: panels are permuted when they cross the C ABI
+// (column-major in caller order <-> row-major panel in block order), every reduction is order independent, and results are
+// for the matrix as the caller defined it.  perm[new] = old.
+// ---------------------------------------------------------------------------------------
+static void fh_block_partition(int64_t N, const std::vector<int>& rowptr, const std::vector<int>& col, int R, std::vector<int>& perm) {
+    perm.clear();
+    perm.reserve(N);
+    std::vector<char> done(N, 0);          // already numbered
+    std::vector<int> gain(N, 0);           // neighbours in the block being grown
+    std::vector<int> stamp(N, -1);         // block id the gain value belongs to
+    std::vector<int> gq;                   // FIFO of vertices adjacent to numbered ones: seeds of later blocks
+    gq.reserve(N);
+    size_t gq_head = 0;
+    int64_t next_unseen = 0;
+    const int MAXG = 64;
+    std::vector<std::vector<int>> bucket(MAXG + 1);
+    int block_id = 0;
+    while ((int64_t)perm.size() < N) {
+        for (auto& b : bucket) b.clear();
+        int top = -1, filled = 0;
+        auto push = [&](int v) {
+            if (stamp[v] != block_id) { stamp[v] = block_id; gain[v] = 0; }
+            const int g = std::min(gain[v], MAXG);
+            bucket[g].push_back(v);
+            top = std::max(top, g);
+        };
+        auto take = [&](int v) {
+            done[v] = 1;
+            perm.push_back(v);
+            ++filled;
+            for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
+                const int u = col[k];
+                if (u == v || done[u]) continue;
+                if (stamp[u] != block_id) { stamp[u] = block_id; gain[u] = 0; }
+                gain[u] += 1;
+                push(u);
+                gq.push_back(u);
+            }
+        };
+        while (filled < R && (int64_t)perm.size() < N) {
+            int v = -1;
+            while (top >= 0) {                                   // frontier vertex with the largest gain (lazy deletion)
+                auto& b = bucket[top];
+                while (!b.empty()) {
+                    const int u = b.back();
+                    b.pop_back();
+                    if (!done[u] && stamp[u] == block_id && std::min(gain[u], MAXG) == top) { v = u; break; }
+                }
+                if (v >= 0) break;
+                --top;
+            }
+            if (v < 0) {                                         // frontier exhausted: new seed, next to numbered vertices if any
+                while (gq_head < gq.size() && done[gq[gq_head]]) ++gq_head;
+                if (gq_head < gq.size()) v = gq[gq_head++];
+                else {
+                    while (next_unseen < N && done[next_unseen]) ++next_unseen;
+                    v = (int)next_unseen;
+                }
+            }
+            take(v);
+        }
+        ++block_id;
+    }
+}
+
 template <typename VT>
 static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage, int64_t nnzA, const int64_t* ptrA,
                          const int64_t* idxA, const VT* valA, int64_t nnzB, const int64_t* ptrB, const int64_t* idxB,
@@ -310,6 +382,32 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
         }
     fh_free_problem(h);
     h->csr_kl = kl_; h->csr_ku = ku_;
+    // Renumber into row blocks when the pattern is too wide for the banded LU anyway (that solver needs caller order)
+    std::vector<int> perm;
+    static const int reorder_mode = getenv("FH_REORDER") ? atoi(getenv("FH_REORDER")) : 1;
+    // (FH_REORDER=0: never; 2: whenever there are at least two blocks -- test rigs push small problems through it)
+    if ((reorder_mode == 1 && N >= 4 * FH_SPMM_R && kl_ + ku_ > 512) || (reorder_mode == 2 && N >= 2 * FH_SPMM_R)) {
+        fh_block_partition(N, rowptr, col, FH_SPMM_R, perm);
+        std::vector<int> inv(N);
+        for (int64_t i = 0; i < N; ++i) inv[perm[i]] = (int)i;
+        std::vector<int> rp2(N + 1, 0), col2(col.size());
+        std::vector<VT> av2(av.size()), bv2(bv.size());
+        std::vector<std::pair<int, int>> row;
+        for (int64_t i = 0; i < N; ++i) {
+            const int o = perm[i];
+            row.clear();
+            for (int k = rowptr[o]; k < rowptr[o + 1]; ++k) row.push_back({inv[col[k]], k});
+            std::sort(row.begin(), row.end());
+            int w = rp2[i];
+            for (auto& e : row) {
+                col2[w] = e.first; av2[w] = av[e.second];
+                if (hasB) bv2[w] = bv[e.second];
+                ++w;
+            }
+            rp2[i + 1] = w;
+        }
+        rowptr.swap(rp2); col.swap(col2); av.swap(av2); bv.swap(bv2);
+    }
     fh_csr& d = h->csr;
     d.N = N; d.nnz = (int64_t)col.size(); d.is_complex = sizeof(VT) == sizeof(cplx); d.b_identity = hasB ? 0 : 1;
     FH_CHECK(hipMalloc((void**)&d.rowptr, (N + 1) * sizeof(int)));
@@ -321,6 +419,10 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
     if (hasB) {
         FH_CHECK(hipMalloc(&d.bval, std::max<size_t>(1, col.size()) * sizeof(VT)));
         FH_CHECK(hipMemcpy(d.bval, bv.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
+    }
+    if (!perm.empty()) {
+        FH_CHECK(hipMalloc((void**)&d.perm, N * sizeof(int)));
+        FH_CHECK(hipMemcpy(d.perm, perm.data(), N * sizeof(int), hipMemcpyHostToDevice));
     }
     h->kind = 2;
     return 0;
@@ -490,6 +592,8 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
 static int fh_op_nblk(feasthip_ctx* h, int ld) {
     return h->kind == 2 ? fh_spmm_partials((int)h->csr.N, ld) : fh_dense_op_nblk((int)h->dense.N);
 }
+// row permutation of the panels (block order of a renumbered sparse matrix), or null
+static const int* fh_perm(feasthip_ctx* h) { return h->kind == 2 ? h->csr.perm : nullptr; }
 static int64_t fh_N(feasthip_ctx* h) { return h->kind == 2 ? h->csr.N : h->dense.N; }
 static bool fh_b_identity(feasthip_ctx* h) { return h->kind == 2 ? h->csr.b_identity != 0 : h->dense.b_identity != 0; }
 
@@ -1025,7 +1129,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     cplx* Qp = (cplx*)p;
     if ((rc = fh_get_buf(h, "ca_out", panel * sizeof(cplx), &p))) return rc;
     cplx* Outp = (cplx*)p;
-    fh_launch_to_panel(dQ, N, N, m, Qp, ld, h->stream);
+    fh_launch_to_panel(dQ, N, N, m, Qp, ld, h->stream, fh_perm(h));
     if (stats) memset(stats, 0, sizeof(*stats));
     if (nodes == 0) {
         FH_CHECK(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream));
@@ -1076,6 +1180,10 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         if (rc) return rc;
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
+        if (h->kind == 2 && h->csr.perm) {
+            h->last_error = "banded LU needs the matrix in the caller's order; this pattern is too wide for it (renumbered into row blocks at ingest)";
+            return FEASTHIP_ERROR_FPM;
+        }
         int64_t nfact = 0;
         rc = fh_banded_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
         if (rc) return rc;
@@ -1193,7 +1301,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         fh_launch_accumulate(Y, panel, dw, nodes, N, ld, sum_acc, Outp, h->real_projection, h->stream);
     }
     fh_prof_end(h);
-    fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream);
+    fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream, fh_perm(h));
 
     // optional moments (variant B): zAq += w_e Q^H Y_e ; zSq += w_e z_e Q^H Y_e
     if (dzAq || dzSq || mom) {
@@ -1212,7 +1320,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         for (int r0 = 0; r0 < m_all; r0 += ld) {
             const int mr_ = std::min(ld, m_all - r0);
             if (mom) {
-                fh_launch_to_panel(mom->dQ_all + (size_t)r0 * N, N, N, mr_, Qrow, ld, h->stream);
+                fh_launch_to_panel(mom->dQ_all + (size_t)r0 * N, N, N, mr_, Qrow, ld, h->stream, fh_perm(h));
             }
             for (int e = 0; e < nodes; ++e) {
                 fh_prof_begin(h, "gram");
@@ -1707,7 +1815,7 @@ static int fh_ortho_wide(feasthip_ctx* h, int m, cplx* dQ, double rank_tol, int*
     std::vector<cplx> dots(ld);
     for (int j = 0; j < npan; ++j) {
         const int mj = std::min(ld, m - j * ld);
-        fh_launch_to_panel(dQ + (size_t)j * ld * N, N, N, mj, X, ld, h->stream);
+        fh_launch_to_panel(dQ + (size_t)j * ld * N, N, N, mj, X, ld, h->stream, fh_perm(h));
         fh_launch_dot_cols(X, X, N, ld, part, ddots, h->stream);
         FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
         FH_CHECK(hipStreamSynchronize(h->stream));
@@ -1716,11 +1824,11 @@ static int fh_ortho_wide(feasthip_ctx* h, int m, cplx* dQ, double rank_tol, int*
     int kept = 0;
     for (int j = 0; j < npan; ++j) {
         const int mj = std::min(ld, m - j * ld);
-        fh_launch_to_panel(dQ + (size_t)j * ld * N, N, N, mj, X, ld, h->stream);
+        fh_launch_to_panel(dQ + (size_t)j * ld * N, N, N, mj, X, ld, h->stream, fh_perm(h));
         for (int pass = 0; pass < 2; ++pass) {
             for (int k0 = 0; k0 < kept; k0 += ld) {
                 const int kw = std::min(ld, kept - k0);
-                fh_launch_to_panel(dQ + (size_t)k0 * N, N, N, kw, K, ld, h->stream);
+                fh_launch_to_panel(dQ + (size_t)k0 * N, N, N, kw, K, ld, h->stream, fh_perm(h));
                 fh_prof_begin(h, "gram");
                 fh_launch_gram(K, X, N, ld, 0, gw, C, h->stream);        // C = K^H X
                 fh_prof_end(h);
@@ -1733,7 +1841,7 @@ static int fh_ortho_wide(feasthip_ctx* h, int m, cplx* dQ, double rank_tol, int*
         int rj = 0;
         cplx* res = nullptr;
         if ((rc = fh_ortho_panel(h, mj, ld, X, Out, rank_tol, ref, m, &rj, &res))) return rc;
-        if (rj > 0) fh_launch_from_panel(res, ld, N, rj, dQ + (size_t)kept * N, N, h->stream);
+        if (rj > 0) fh_launch_from_panel(res, ld, N, rj, dQ + (size_t)kept * N, N, h->stream, fh_perm(h));
         kept += rj;
     }
     *rank = kept;
@@ -1758,10 +1866,10 @@ extern "C" int feasthip_orthonormalize_dev(feasthip_handle h, int64_t m64, void*
     cplx* X = (cplx*)p;
     if ((rc = fh_get_buf(h, "or_out", panel * sizeof(cplx), &p))) return rc;
     cplx* Out = (cplx*)p;
-    fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream);
+    fh_launch_to_panel((const cplx*)dQ, N, N, m, X, ld, h->stream, fh_perm(h));
     cplx* res = nullptr;
     if ((rc = fh_ortho_panel(h, m, ld, X, Out, rank_tol, 0.0, m, rank, &res))) return rc;
-    fh_launch_from_panel(res, ld, N, m, (cplx*)dQ, N, h->stream);
+    fh_launch_from_panel(res, ld, N, m, (cplx*)dQ, N, h->stream, fh_perm(h));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
     FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
@@ -1833,7 +1941,7 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
             } else {
                 for (int j = 0; j < npan; ++j) {
                     const int mj = std::min(ld, r - j * ld);
-                    fh_launch_to_panel((const cplx*)dQ + (size_t)j * ld * N, N, N, mj, Qj, ld, h->stream);
+                    fh_launch_to_panel((const cplx*)dQ + (size_t)j * ld * N, N, N, mj, Qj, ld, h->stream, fh_perm(h));
                     fh_op_call oc;
                     oc.m = mj;
                     oc.X = Qj; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
@@ -1843,7 +1951,7 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
                     fh_apply_operator(h, ld, oc);
                     for (int i = 0; i < npan; ++i) {
                         const int mi = std::min(ld, r - i * ld);
-                        fh_launch_to_panel((const cplx*)dQ + (size_t)i * ld * N, N, N, mi, Qi, ld, h->stream);
+                        fh_launch_to_panel((const cplx*)dQ + (size_t)i * ld * N, N, N, mi, Qi, ld, h->stream, fh_perm(h));
                         fh_prof_begin(h, "gram");
                         fh_launch_gram(Qi, W, N, ld, bilinear, gw, G, h->stream);
                         fh_prof_end(h);
@@ -1877,7 +1985,7 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
     cplx* gw = (cplx*)p;
     if ((rc = fh_get_buf(h, "gram_G", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
     cplx* G = (cplx*)p;
-    fh_launch_to_panel((const cplx*)dQ, N, N, r, Qp, ld, h->stream);
+    fh_launch_to_panel((const cplx*)dQ, N, N, r, Qp, ld, h->stream, fh_perm(h));
     std::vector<cplx> one(ld, cmake(1, 0)), zero(ld, cmake(0, 0));
     cplx *d1, *d0;
     if ((rc = fh_upload_coefs(h, "pj_one", one, &d1))) return rc;
@@ -1972,7 +2080,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
                 for (int c2 = 0; c2 < mj; ++c2)
                     for (int c1 = 0; c1 < mi; ++c1) Vp[(size_t)c2 * ld + c1] = Vh[(size_t)(j * ld + c2) * r + i * ld + c1];
                 FH_CHECK(hipMemcpyAsync(dV, Vp.data(), Vp.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
-                fh_launch_to_panel((const cplx*)dQ + (size_t)i * ld * N, N, N, mi, Qp, ld, h->stream);
+                fh_launch_to_panel((const cplx*)dQ + (size_t)i * ld * N, N, N, mi, Qp, ld, h->stream, fh_perm(h));
                 fh_prof_begin(h, "ritz");
                 if (i == 0) {
                     fh_launch_small_matmul(Qp, dV, N, ld, Xp, h->stream);
@@ -1997,7 +2105,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
                 if ((rc = fh_upload_coefs(h, "rz_scale", sc, &dsc))) return rc;
                 fh_launch_scale_cols(Xp, dsc, N, ld, h->stream);
             }
-            fh_launch_from_panel(Xp, ld, N, mj, (cplx*)dX + (size_t)j * ld * N, N, h->stream);
+            fh_launch_from_panel(Xp, ld, N, mj, (cplx*)dX + (size_t)j * ld * N, N, h->stream, fh_perm(h));
             if (Mj > 0 && res_host) {
                 const double* lam = lambda_host + 2 * (size_t)j * ld;
                 std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
@@ -2059,7 +2167,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
     const cplx* Vh = (const cplx*)V_host;
     for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) Vp[(size_t)j * ld + i] = Vh[(size_t)j * r + i];
     FH_CHECK(hipMemcpyAsync(dV, Vp.data(), Vp.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
-    fh_launch_to_panel((const cplx*)dQ, N, N, r, Qp, ld, h->stream);
+    fh_launch_to_panel((const cplx*)dQ, N, N, r, Qp, ld, h->stream, fh_perm(h));
     fh_prof_begin(h, "ritz");
     fh_launch_small_matmul(Qp, dV, N, ld, Xp, h->stream);
     fh_prof_end(h);
@@ -2078,7 +2186,7 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
         if ((rc = fh_upload_coefs(h, "rz_scale", sc, &dsc))) return rc;
         fh_launch_scale_cols(Xp, dsc, N, ld, h->stream);
     }
-    fh_launch_from_panel(Xp, ld, N, r, (cplx*)dX, N, h->stream);
+    fh_launch_from_panel(Xp, ld, N, r, (cplx*)dX, N, h->stream, fh_perm(h));
     if (M > 0 && res_host) {
         // R = A X - B X diag(lambda); res_j = ||R_j|| / max(|lambda_j|, 1)
         std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
@@ -2223,7 +2331,7 @@ extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, co
     cplx* Xp = (cplx*)p;
     if ((rc = fh_get_buf(h, "mm_Y", panel * sizeof(cplx), &p))) return rc;
     cplx* Yp = (cplx*)p;
-    fh_launch_to_panel((const cplx*)dX, N, N, m, Xp, ld, h->stream);
+    fh_launch_to_panel((const cplx*)dX, N, N, m, Xp, ld, h->stream, fh_perm(h));
     std::vector<cplx> ca(ld, cmake(which == 0 ? 1 : 0, 0)), cb(ld, cmake(which == 1 ? 1 : 0, 0));
     cplx *dca, *dcb;
     if ((rc = fh_upload_coefs(h, "mm_coefA", ca, &dca))) return rc;
@@ -2234,7 +2342,7 @@ extern "C" int feasthip_matmul_dev(feasthip_handle h, int which, int64_t m64, co
     oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
     oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
     fh_apply_operator(h, ld, oc);
-    fh_launch_from_panel(Yp, ld, N, m, (cplx*)dY, N, h->stream);
+    fh_launch_from_panel(Yp, ld, N, m, (cplx*)dY, N, h->stream, fh_perm(h));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
     FH_CHECK(hipGetLastError());       // launch-configuration errors do not surface through the stream sync
@@ -2290,7 +2398,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
     if ((rc = fh_get_buf(h, "ss_Y", panel * sizeof(cplx), &p))) return rc;
     cplx* Y = (cplx*)p;
     if (stats) memset(stats, 0, sizeof(*stats));
-    fh_launch_to_panel((const cplx*)dX, N, N, m, Rhs, ld, h->stream);
+    fh_launch_to_panel((const cplx*)dX, N, N, m, Rhs, ld, h->stream, fh_perm(h));
     std::vector<cplx> z(1, cmake(z_re, z_im));
     std::vector<int> status(1, 0);
     if (h->solver == FEASTHIP_SOLVER_LU) {
@@ -2303,6 +2411,10 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         if (rc) return rc;
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
+        if (h->kind == 2 && h->csr.perm) {
+            h->last_error = "banded LU needs the matrix in the caller's order; this pattern is too wide for it (renumbered into row blocks at ingest)";
+            return FEASTHIP_ERROR_FPM;
+        }
         int64_t nfact = 0;
         rc = fh_banded_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;
@@ -2326,7 +2438,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         status = sr.status;
         if (stats) { stats->krylov_iterations = sr.iters_sum; stats->spmm_calls = sr.op_calls; stats->max_rel_residual = sr.max_rel_res; }
     }
-    fh_launch_from_panel(Y, ld, N, m, (cplx*)dY, N, h->stream);
+    fh_launch_from_panel(Y, ld, N, m, (cplx*)dY, N, h->stream, fh_perm(h));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
     return status[0];

@@ -17,16 +17,17 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 template <typename ST>
 __global__ __launch_bounds__(FH_BLOCK) void k_to_panel(const ST* __restrict__ src, int64_t lds, int N, int m,
-                                                        cplx* __restrict__ dst, int ld) {
+                                                        cplx* __restrict__ dst, int ld, const int* __restrict__ perm) {
     __shared__ cplx tile[64][65];
     const int i0 = blockIdx.x * 64;
     const int t = threadIdx.x;
     const int ti = t & 63, tc = t >> 6;
+    const int srow = (i0 + ti < N) ? (perm ? perm[i0 + ti] : i0 + ti) : 0;      // caller's row behind panel row i0 + ti
     for (int c = tc; c < ld; c += 4) {
         cplx v = cmake(0, 0);
         if (c < m && i0 + ti < N) {
-            if constexpr (sizeof(ST) == sizeof(cplx)) v = ((const cplx*)src)[(size_t)c * lds + i0 + ti];
-            else v = cmake(((const double*)src)[(size_t)c * lds + i0 + ti], 0.0);
+            if constexpr (sizeof(ST) == sizeof(cplx)) v = ((const cplx*)src)[(size_t)c * lds + srow];
+            else v = cmake(((const double*)src)[(size_t)c * lds + srow], 0.0);
         }
         tile[c][ti] = v;
     }
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_to_panel(const ST* __restrict__ sr
 }
 
 __global__ __launch_bounds__(FH_BLOCK) void k_from_panel(const cplx* __restrict__ src, int ld, int N, int m,
-                                                          cplx* __restrict__ dst, int64_t ldd) {
+                                                          cplx* __restrict__ dst, int64_t ldd, const int* __restrict__ perm) {
     __shared__ cplx tile[64][65];
     const int i0 = blockIdx.x * 64;
     const int t = threadIdx.x;
@@ -48,18 +49,19 @@ __global__ __launch_bounds__(FH_BLOCK) void k_from_panel(const cplx* __restrict_
     }
     __syncthreads();
     const int ti = t & 63, tc = t >> 6;
+    const int drow = (i0 + ti < N) ? (perm ? perm[i0 + ti] : i0 + ti) : 0;
     for (int c = tc; c < m; c += 4)
-        if (i0 + ti < N) dst[(size_t)c * ldd + i0 + ti] = tile[c][ti];
+        if (i0 + ti < N) dst[(size_t)c * ldd + drow] = tile[c][ti];
 }
 
-void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st) {
-    hipLaunchKernelGGL((k_to_panel<cplx>), dim3((N + 63) / 64), dim3(FH_BLOCK), 0, st, src, lds, N, m, dst, ld);
+void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st, const int* perm) {
+    hipLaunchKernelGGL((k_to_panel<cplx>), dim3((N + 63) / 64), dim3(FH_BLOCK), 0, st, src, lds, N, m, dst, ld, perm);
 }
 void fh_launch_to_panel_real(const double* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st) {
-    hipLaunchKernelGGL((k_to_panel<double>), dim3((N + 63) / 64), dim3(FH_BLOCK), 0, st, src, lds, N, m, dst, ld);
+    hipLaunchKernelGGL((k_to_panel<double>), dim3((N + 63) / 64), dim3(FH_BLOCK), 0, st, src, lds, N, m, dst, ld, (const int*)nullptr);
 }
-void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int64_t ldd, hipStream_t st) {
-    hipLaunchKernelGGL(k_from_panel, dim3((N + 63) / 64), dim3(FH_BLOCK), 0, st, src, ld, N, m, dst, ldd);
+void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int64_t ldd, hipStream_t st, const int* perm) {
+    hipLaunchKernelGGL(k_from_panel, dim3((N + 63) / 64), dim3(FH_BLOCK), 0, st, src, ld, N, m, dst, ldd, perm);
 }
 
 // ---------------------------------------------------------------------------------------

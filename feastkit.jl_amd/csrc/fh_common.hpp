@@ -85,7 +85,9 @@ struct fh_csr {
     int* col = nullptr;      // nnz
     void* aval = nullptr;    // nnz x (double|cplx), A on the union pattern
     void* bval = nullptr;    // nnz x (double|cplx), B on the union pattern (null if identity)
+    int* perm = nullptr;     // N: row/column renumbering applied at ingest, perm[internal] = caller's index (null: none)
 };
+#define FH_SPMM_R 256        // rows per block of the ingest renumbering / the LDS-window SpMM
 
 struct fh_dense {
     int64_t N = 0;

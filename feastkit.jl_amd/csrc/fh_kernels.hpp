@@ -107,8 +107,9 @@ void fh_launch_gm_finish_cycle(const fh_gmres_args& a, int ld, cplx* X, size_t x
 
 // ---- block (panel) operations ------------------------------------------------------------
 // column-major (N x m, leading dim lds) <-> row-major panel (N x ld), zero padded
-void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
-void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int64_t ldd, hipStream_t st);
+// perm != null: panel row i holds the caller's row perm[i] (block order of a renumbered sparse matrix)
+void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st, const int* perm = nullptr);
+void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int64_t ldd, hipStream_t st, const int* perm = nullptr);
 // real column-major source -> complex panel
 void fh_launch_to_panel_real(const double* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
 // dst = sum_e w[e] * X[e]
