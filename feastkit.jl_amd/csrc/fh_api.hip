@@ -164,6 +164,10 @@ static void fh_free_problem(feasthip_ctx* h) {
     if (h->csr.aval) hipFree(h->csr.aval);
     if (h->csr.bval) hipFree(h->csr.bval);
     if (h->csr.perm) hipFree(h->csr.perm);
+    if (h->csr.blk_start) hipFree(h->csr.blk_start);
+    if (h->csr.ext_ptr) hipFree(h->csr.ext_ptr);
+    if (h->csr.ext_idx) hipFree(h->csr.ext_idx);
+    if (h->csr.lcol) hipFree(h->csr.lcol);
     h->csr = fh_csr();
     if (h->dense.A) hipFree(h->dense.A);
     if (h->dense.B) hipFree(h->dense.B);
@@ -267,74 +271,68 @@ static inline double vadd(double a, double b) { return a + b; }
 static inline cplx vadd(cplx a, cplx b) { return cadd(a, b); }
 
 // ---------------------------------------------------------------------------------------
-// Row blocks for the LDS-window SpMM (fh_sparse.hip).  The hot SpMM stages the X rows a block of FH_SPMM_R consecutive
-// matrix rows touches into LDS; that only pays when most of a block's column indices fall inside the block itself.
-// Ingest therefore renumbers the unknowns: greedy graph growing on the union pattern (the GGGP seed/grow step of
-// multilevel partitioners: always add the frontier vertex with the most neighbours already in the block), blocks filled to
-// exactly FH_SPMM_R rows, the next block seeded next to the previous ones so that neighbouring blocks get neighbouring
-// numbers.  The permutation never leaves the library: panels are permuted when they cross the C ABI
-// (column-major in caller order <-> row-major panel in block order), every reduction is order independent, and results are
-// for the matrix as the caller defined it.  perm[new] = old.
+// Row blocks for the LDS-window SpMM (fh_sparse.hip).  That kernel stages the X rows a block of at most FH_SPMM_R
+// consecutive matrix rows touches into LDS; it only pays when most of a block's column indices fall inside the block and
+// the rest hit few distinct rows.  Ingest therefore renumbers the unknowns by recursive bisection of the union pattern:
+// breadth-first levels from a pseudo-peripheral vertex of the part, cut at a multiple of FH_SPMM_R near the middle, both
+// halves again, until a part fits one block.  On the 7-point pattern of cfg 3 a 128-row block reaches 133 distinct
+// outside rows on average (greedy graph growing, tried first: 281).  The permutation never leaves the library: panels are
+// permuted when they cross the C ABI (column-major in caller order <-> row-major panel in block order), every reduction is
+// order independent, results are for the matrix as the caller defined it.  perm[new] = old; blk_start: first row of every
+// block (+ N).
 // ---------------------------------------------------------------------------------------
-static void fh_block_partition(int64_t N, const std::vector<int>& rowptr, const std::vector<int>& col, int R, std::vector<int>& perm) {
-    perm.clear();
-    perm.reserve(N);
-    std::vector<char> done(N, 0);          // already numbered
-    std::vector<int> gain(N, 0);           // neighbours in the block being grown
-    std::vector<int> stamp(N, -1);         // block id the gain value belongs to
-    std::vector<int> gq;                   // FIFO of vertices adjacent to numbered ones: seeds of later blocks
-    gq.reserve(N);
-    size_t gq_head = 0;
-    int64_t next_unseen = 0;
-    const int MAXG = 64;
-    std::vector<std::vector<int>> bucket(MAXG + 1);
-    int block_id = 0;
-    while ((int64_t)perm.size() < N) {
-        for (auto& b : bucket) b.clear();
-        int top = -1, filled = 0;
-        auto push = [&](int v) {
-            if (stamp[v] != block_id) { stamp[v] = block_id; gain[v] = 0; }
-            const int g = std::min(gain[v], MAXG);
-            bucket[g].push_back(v);
-            top = std::max(top, g);
-        };
-        auto take = [&](int v) {
-            done[v] = 1;
-            perm.push_back(v);
-            ++filled;
+static void fh_block_partition(int64_t N, const std::vector<int>& rowptr, const std::vector<int>& col, int R,
+                               std::vector<int>& perm, std::vector<int>& blk_start) {
+    perm.resize(N);
+    for (int64_t i = 0; i < N; ++i) perm[i] = (int)i;
+    blk_start.clear();
+    std::vector<int> part(N, 0), seen(N, -1), buf, probe;
+    buf.reserve(N);
+    int next_pid = 1, next_id = 0;
+    // breadth-first order of part `pid` from `start` (marks: seen[v] = id), appended to out; returns the last vertex reached
+    auto bfs = [&](int start, int pid, int id, std::vector<int>& out) -> int {
+        const size_t first = out.size();
+        seen[start] = id;
+        out.push_back(start);
+        for (size_t head = first; head < out.size(); ++head) {
+            const int v = out[head];
             for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
                 const int u = col[k];
-                if (u == v || done[u]) continue;
-                if (stamp[u] != block_id) { stamp[u] = block_id; gain[u] = 0; }
-                gain[u] += 1;
-                push(u);
-                gq.push_back(u);
+                if (part[u] == pid && seen[u] != id) { seen[u] = id; out.push_back(u); }
             }
-        };
-        while (filled < R && (int64_t)perm.size() < N) {
-            int v = -1;
-            while (top >= 0) {                                   // frontier vertex with the largest gain (lazy deletion)
-                auto& b = bucket[top];
-                while (!b.empty()) {
-                    const int u = b.back();
-                    b.pop_back();
-                    if (!done[u] && stamp[u] == block_id && std::min(gain[u], MAXG) == top) { v = u; break; }
-                }
-                if (v >= 0) break;
-                --top;
-            }
-            if (v < 0) {                                         // frontier exhausted: new seed, next to numbered vertices if any
-                while (gq_head < gq.size() && done[gq[gq_head]]) ++gq_head;
-                if (gq_head < gq.size()) v = gq[gq_head++];
-                else {
-                    while (next_unseen < N && done[next_unseen]) ++next_unseen;
-                    v = (int)next_unseen;
-                }
-            }
-            take(v);
         }
-        ++block_id;
+        return out.back();
+    };
+    struct range { int64_t lo, hi; int pid; };
+    std::vector<range> stack, leaves;
+    stack.push_back({0, N, 0});
+    while (!stack.empty()) {
+        const range r = stack.back();
+        stack.pop_back();
+        const int64_t n = r.hi - r.lo;
+        if (n <= R) { leaves.push_back(r); continue; }
+        // level order of the part: every connected component from a pseudo-peripheral vertex (the far end of a probe BFS)
+        const int id_probe = next_id++, id_order = next_id++;
+        buf.clear();
+        for (int64_t i = r.lo; i < r.hi; ++i) {
+            const int v = perm[i];
+            if (seen[v] == id_order) continue;                 // placed with an earlier component
+            probe.clear();
+            const int far = bfs(v, r.pid, id_probe, probe);
+            bfs(far, r.pid, id_order, buf);
+        }
+        for (int64_t i = 0; i < n; ++i) perm[r.lo + i] = buf[i];
+        int64_t left = ((n / 2 + R / 2) / R) * R;              // cut at a multiple of R near the middle: full blocks
+        left = std::max<int64_t>(R, std::min<int64_t>(left, n - 1));
+        const int p1 = next_pid++, p2 = next_pid++;
+        for (int64_t i = 0; i < left; ++i) part[perm[r.lo + i]] = p1;
+        for (int64_t i = left; i < n; ++i) part[perm[r.lo + i]] = p2;
+        stack.push_back({r.lo + left, r.hi, p2});
+        stack.push_back({r.lo, r.lo + left, p1});
     }
+    std::sort(leaves.begin(), leaves.end(), [](const range& a, const range& b) { return a.lo < b.lo; });
+    for (const range& r : leaves) blk_start.push_back((int)r.lo);
+    blk_start.push_back((int)N);
 }
 
 template <typename VT>
@@ -383,11 +381,13 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
     fh_free_problem(h);
     h->csr_kl = kl_; h->csr_ku = ku_;
     // Renumber into row blocks when the pattern is too wide for the banded LU anyway (that solver needs caller order)
-    std::vector<int> perm;
-    static const int reorder_mode = getenv("FH_REORDER") ? atoi(getenv("FH_REORDER")) : 1;
-    // (FH_REORDER=0: never; 2: whenever there are at least two blocks -- test rigs push small problems through it)
+    std::vector<int> perm, blk_start;
+    // OFF by default: the LDS-window SpMM it feeds measured slower than the gather kernel on cfg 3 (57 vs 33 us per node,
+    // DESIGN.md section 5) -- FH_REORDER=1 renumbers wide-band matrices and switches that kernel on, FH_REORDER=2 does so
+    // whenever there are at least two blocks (test rigs push small problems through it)
+    static const int reorder_mode = getenv("FH_REORDER") ? atoi(getenv("FH_REORDER")) : 0;
     if ((reorder_mode == 1 && N >= 4 * FH_SPMM_R && kl_ + ku_ > 512) || (reorder_mode == 2 && N >= 2 * FH_SPMM_R)) {
-        fh_block_partition(N, rowptr, col, FH_SPMM_R, perm);
+        fh_block_partition(N, rowptr, col, FH_SPMM_R, perm, blk_start);
         std::vector<int> inv(N);
         for (int64_t i = 0; i < N; ++i) inv[perm[i]] = (int)i;
         std::vector<int> rp2(N + 1, 0), col2(col.size());
@@ -423,6 +423,40 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
     if (!perm.empty()) {
         FH_CHECK(hipMalloc((void**)&d.perm, N * sizeof(int)));
         FH_CHECK(hipMemcpy(d.perm, perm.data(), N * sizeof(int), hipMemcpyHostToDevice));
+        // LDS slots of every nonzero
+        const int nb = (int)blk_start.size() - 1;
+        std::vector<int> ext_ptr(nb + 1, 0), ext_idx;
+        std::vector<unsigned short> lcol(col.size(), 0);
+        std::vector<int> uniq;
+        for (int b = 0; b < nb; ++b) {
+            const int r0 = blk_start[b], r1 = blk_start[b + 1];
+            uniq.clear();
+            for (int k = rowptr[r0]; k < rowptr[r1]; ++k) if (col[k] < r0 || col[k] >= r1) uniq.push_back(col[k]);
+            std::sort(uniq.begin(), uniq.end());
+            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+            if ((int)uniq.size() > FH_SPMM_EXT) uniq.resize(FH_SPMM_EXT);       // the rest is gathered from global memory
+            for (int k = rowptr[r0]; k < rowptr[r1]; ++k) {
+                const int c = col[k];
+                if (c >= r0 && c < r1) lcol[k] = (unsigned short)(c - r0);
+                else {
+                    auto it = std::lower_bound(uniq.begin(), uniq.end(), c);
+                    lcol[k] = (it != uniq.end() && *it == c) ? (unsigned short)(FH_SPMM_R + (it - uniq.begin())) : (unsigned short)0xFFFF;
+                }
+            }
+            ext_idx.insert(ext_idx.end(), uniq.begin(), uniq.end());
+            ext_ptr[b + 1] = (int)ext_idx.size();
+        }
+        d.nblk = nb;
+        FH_CHECK(hipMalloc((void**)&d.blk_start, (nb + 1) * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.ext_ptr, (nb + 1) * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.ext_idx, std::max<size_t>(1, ext_idx.size()) * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.lcol, std::max<size_t>(1, lcol.size()) * sizeof(unsigned short)));
+        FH_CHECK(hipMemcpy(d.blk_start, blk_start.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.ext_ptr, ext_ptr.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.ext_idx, ext_idx.data(), ext_idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.lcol, lcol.data(), lcol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        if (getenv("FH_DEBUG_TIMING"))
+            fprintf(stderr, "[feasthip] renumbered into %d row blocks, %.1f outside rows per block on average\n", nb, nb ? (double)ext_idx.size() / nb : 0.0);
     }
     h->kind = 2;
     return 0;
@@ -570,9 +604,14 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
         a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
         a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m; a.uniform_coef = c.uniform_coef; a.prec = c.prec;
+        static const bool no_lds = getenv("FH_NO_LDS_SPMM") != nullptr;
+        const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds;
+        a.nblk_rows = h->csr.nblk; a.blk_start = h->csr.blk_start; a.ext_ptr = h->csr.ext_ptr; a.ext_idx = h->csr.ext_idx;
+        a.lcol = lds_kernel ? h->csr.lcol : nullptr;
         fh_prof_begin(h, "spmm");
         fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, fh_spmm_grid(a.N, ld), h->stream);
         fh_prof_end(h);
+        if (lds_kernel) return (8 / (ld / 16)) * fh_spmm_lds_slots(a.nblk_rows, ld);
         return fh_spmm_partials(a.N, ld);     // partial-sum rows per node
     }
     fh_dense_op_args a;
@@ -590,7 +629,10 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
 }
 
 static int fh_op_nblk(feasthip_ctx* h, int ld) {
-    return h->kind == 2 ? fh_spmm_partials((int)h->csr.N, ld) : fh_dense_op_nblk((int)h->dense.N);
+    // (an upper bound is enough here: it sizes the partial-sum buffers; the row count used by the finalize kernels is what
+    //  fh_apply_operator returns for the kernel it actually launched)
+    if (h->kind == 2) return std::max(fh_spmm_partials((int)h->csr.N, ld), h->csr.lcol ? (8 / (ld / 16)) * fh_spmm_lds_slots(h->csr.nblk, ld) : 0);
+    return fh_dense_op_nblk((int)h->dense.N);
 }
 // row permutation of the panels (block order of a renumbered sparse matrix), or null
 static const int* fh_perm(feasthip_ctx* h) { return h->kind == 2 ? h->csr.perm : nullptr; }

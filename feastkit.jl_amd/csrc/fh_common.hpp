@@ -86,8 +86,18 @@ struct fh_csr {
     void* aval = nullptr;    // nnz x (double|cplx), A on the union pattern
     void* bval = nullptr;    // nnz x (double|cplx), B on the union pattern (null if identity)
     int* perm = nullptr;     // N: row/column renumbering applied at ingest, perm[internal] = caller's index (null: none)
+    // row blocks of the renumbered matrix (LDS-window SpMM): block b = rows [blk_start[b], blk_start[b+1]) (<= FH_SPMM_R),
+    // ext_idx[ext_ptr[b] .. ext_ptr[b+1]) = the distinct rows OUTSIDE the block its nonzeros touch (<= FH_SPMM_EXT kept),
+    // lcol[k] = LDS slot of nonzero k: row - blk_start[b] inside the block, FH_SPMM_R + position in the block's ext list
+    // outside, 0xFFFF when the ext list was full (the kernel then gathers col[k] from global memory)
+    int nblk = 0;
+    int* blk_start = nullptr;
+    int* ext_ptr = nullptr;
+    int* ext_idx = nullptr;
+    unsigned short* lcol = nullptr;
 };
-#define FH_SPMM_R 256        // rows per block of the ingest renumbering / the LDS-window SpMM
+#define FH_SPMM_R 128        // rows per block of the ingest renumbering / the LDS-window SpMM
+#define FH_SPMM_EXT 160      // outside rows a block stages next to its own: (128 + 160) x 256 B = 72 KiB of LDS, two blocks per CU
 
 struct fh_dense {
     int64_t N = 0;

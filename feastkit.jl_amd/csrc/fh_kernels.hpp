@@ -19,9 +19,12 @@ struct fh_spmm_args {
     int m;                                    // active width when node_active is null
     int uniform_coef;                         // coefA/coefB identical for every column of a node
     int prec;                                 // 64 | 32
+    // row blocks of a renumbered matrix (fh_common.hpp: fh_csr); lcol == null: not renumbered, k_spmm serves
+    int nblk_rows; const int* blk_start; const int* ext_ptr; const int* ext_idx; const unsigned short* lcol;
 };
 int fh_spmm_grid(int N, int ld);
 int fh_spmm_partials(int N, int ld);
+int fh_spmm_lds_slots(int nblk_rows, int ld);
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st);
 
 // ---- Krylov vector kernels (BiCGStab and COCG) -------------------------------------------

@@ -73,6 +73,24 @@ int fh_spmm_partials(int N, int ld) { return (8 / (ld / 16)) * fh_spmm_slots(N, 
 __device__ __forceinline__ double fh_shfl16(double v, int src) { return __shfl(v, src, 16); }
 __device__ __forceinline__ cplx fh_shfl16(cplx v, int src) { return cmake(__shfl(v.x, src, 16), __shfl(v.y, src, 16)); }
 __device__ __forceinline__ cplxf fh_shfl16(cplxf v, int src) { return cmakef(__shfl(v.x, src, 16), __shfl(v.y, src, 16)); }
+// Broadcast of lane q of every 16-lane row to the whole row as a DPP move (v_mov_b32_dpp row_newbcast:q): a VALU
+// instruction, where __shfl(v, q, 16) is a ds_bpermute through the LDS pipe -- 40 of those per matrix row in the SpMM
+// inner loop (8 column indices + 8 complex coefficients).  q must fold to a constant (unrolled loops).
+template <int Q> __device__ __forceinline__ int fh_bc16c(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + Q, 0xF, 0xF, false); }
+__device__ __forceinline__ int fh_bc16(int v, int q) {
+    switch (q & 15) {
+        case 0: return fh_bc16c<0>(v); case 1: return fh_bc16c<1>(v); case 2: return fh_bc16c<2>(v); case 3: return fh_bc16c<3>(v);
+        case 4: return fh_bc16c<4>(v); case 5: return fh_bc16c<5>(v); case 6: return fh_bc16c<6>(v); case 7: return fh_bc16c<7>(v);
+        case 8: return fh_bc16c<8>(v); case 9: return fh_bc16c<9>(v); case 10: return fh_bc16c<10>(v); case 11: return fh_bc16c<11>(v);
+        case 12: return fh_bc16c<12>(v); case 13: return fh_bc16c<13>(v); case 14: return fh_bc16c<14>(v); default: return fh_bc16c<15>(v);
+    }
+}
+__device__ __forceinline__ float fh_bc16(float v, int q) { return __int_as_float(fh_bc16(__float_as_int(v), q)); }
+__device__ __forceinline__ double fh_bc16(double v, int q) {
+    return __hiloint2double(fh_bc16(__double2hiint(v), q), fh_bc16(__double2loint(v), q));
+}
+__device__ __forceinline__ cplx fh_bc16(cplx v, int q) { return cmake(fh_bc16(v.x, q), fh_bc16(v.y, q)); }
+__device__ __forceinline__ cplxf fh_bc16(cplxf v, int q) { return cmakef(fh_bc16(v.x, q), fh_bc16(v.y, q)); }
 __device__ __forceinline__ double fh_vzero(double) { return 0.0; }
 __device__ __forceinline__ cplx fh_vzero(cplx) { return cmake(0, 0); }
 __device__ __forceinline__ cplx fh_ld_nt(const cplx* p) {
@@ -196,17 +214,17 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                     CT xs[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int j = (q0 + q < cnt) ? __shfl(mycol, q0 + q, 16) : i;
+                        const int j = (q0 + q < cnt) ? fh_bc16(mycol, q0 + q) : i;
                         xs[q] = X[(size_t)j * LD + c];
                     }
                     if (a.uniform_coef) {
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) cfma(acc, fh_shfl16(mys, q0 + q), xs[q]);
+                        for (int q = 0; q < 8; ++q) cfma(acc, fh_bc16(mys, q0 + q), xs[q]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
-                            CT sc = vmul(fh_shfl16(mya, q0 + q), ca);        // zero beyond the row end
-                            if (!BIDENT) sc = cadd(sc, vmul(fh_shfl16(myb, q0 + q), cb));
+                            CT sc = vmul(fh_bc16(mya, q0 + q), ca);        // zero beyond the row end
+                            if (!BIDENT) sc = cadd(sc, vmul(fh_bc16(myb, q0 + q), cb));
                             cfma(acc, sc, xs[q]);
                         }
                     }
@@ -252,6 +270,263 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// LDS-window SpMM for a matrix that ingest renumbered into row blocks (fh_api.hip: fh_block_partition; complex128 panels).
+// OPT-IN (FH_REORDER=1|2): measured SLOWER than k_spmm on cfg 3 -- 57 us against 33 us per node -- see below.
+//
+// k_spmm gathers every X row a matrix row touches from L1/L2: 8 gathers of 256 B per row and 16-column tile.  Here a
+// workgroup takes one row block (<= 128 rows) x one 16-column tile and first pulls every X row the block needs -- its
+// own rows and the distinct outside rows its nonzeros touch, listed at ingest (129 per block on cfg 3 after the
+// bisection renumbering) -- into LDS with LDS-DMA row gathers (global_load_lds_dwordx4: per-lane source address, 1 KiB =
+// four 256-B rows per wave-instruction, no VGPRs, all ~260 rows of a block in flight at once), then computes from LDS
+// only: the column index of a nonzero is its LDS slot (uint16).  The matrix rows of a lane group are fetched once per
+// row block into registers and serve every node.  Outside rows beyond the FH_SPMM_EXT kept per block carry slot 0xFFFF
+// and are gathered from global memory.  Same arithmetic order per row as k_spmm, one partial-sum row per workgroup.
+//
+// What the measurement says (one node, 64 columns, tools/mb_spmm.py; phases switched off one at a time): staging costs
+// 7 us of the 57, the per-block set-up 15, the LDS-fed row loop 35 -- the row loop is VALU-bound (about 210 instructions
+// per 4-row step: coefficient and slot broadcasts, fp64 complex FMAs, the register-array selects) at the two waves per
+// SIMD that 72 KiB of LDS per workgroup leave, where k_spmm hides the same arithmetic under its gathers at four.  The
+// window removes L2 requests (8 -> 2 per row), and requests were never what bounded the gather kernel: it runs at the
+// same 33-35 us per node in lexicographic, brick and bisection order alike.
+// ------------------------------------------------------------------------------------
+#define FH_LDS_SLOTS (FH_SPMM_R + FH_SPMM_EXT)
+#define FH_LDS_RPG (FH_SPMM_R / 16)          // rows per 16-lane group and row block (16 groups per workgroup)
+// element s of an 8-entry register array without dynamic indexing (a select chain keeps the array in VGPRs; the row loop is
+// NOT unrolled: eight unrolled rows needed 256 VGPRs and spilled)
+#define FH_SEL8(arr, s) ((s) == 0 ? arr[0] : (s) == 1 ? arr[1] : (s) == 2 ? arr[2] : (s) == 3 ? arr[3] : (s) == 4 ? arr[4] : (s) == 5 ? arr[5] : (s) == 6 ? arr[6] : arr[7])
+static_assert(FH_LDS_RPG == 8, "FH_SEL8 assumes eight rows per lane group");
+template <typename VT, int LD, bool BIDENT>
+__global__ __launch_bounds__(FH_BLOCK, 2) void k_spmm_lds(fh_spmm_args a) {
+    typedef cplx CT;
+    constexpr int NT = LD / 16;
+    constexpr int SLICES = 8 / NT;
+    extern __shared__ cplx lds_x[];                       // FH_LDS_SLOTS rows x 16 columns
+    __shared__ cplx red[FH_BLOCK];
+    __shared__ int s_list[64];
+    __shared__ int s_cnt;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int S = gridDim.x >> 3;
+    const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ct = grp % NT, slice = grp / NT;
+    const int per = (a.nblk_rows + SLICES - 1) / SLICES;   // row blocks per slice
+    const int b_lo = min(a.nblk_rows, slice * per), b_hi = min(a.nblk_rows, b_lo + per);
+    const int c = ct * 16 + l16;
+    const VT* __restrict__ aval = (const VT*)a.aval;
+    const VT* __restrict__ bval = (const VT*)a.bval;
+    const int* __restrict__ rowptr = a.rowptr;
+    const int* __restrict__ colidx = a.col;
+    const unsigned short* __restrict__ lcol = a.lcol;
+    const int prow = slice * S + slot;
+    const int nprow = SLICES * S;
+
+    // active nodes of this launch; inactive ones only get their partial sums cleared
+    if (t == 0) {
+        int n = 0;
+        for (int node = 0; node < a.nodes && n < 64; ++node)
+            if (!a.node_active || a.node_active[node] != 0) s_list[n++] = node;
+        s_cnt = n;
+    }
+    if (a.dot_mode != 0 && t < 16) {
+        // cleared for EVERY node: the row blocks below add their contributions one after the other
+        for (int node = 0; node < a.nodes; ++node) {
+            const size_t pb = ((size_t)node * nprow + prow) * LD + ct * 16;
+            if (a.partial1) a.partial1[pb + t] = cmake(0, 0);
+            if (a.partial2) a.partial2[pb + t] = cmake(0, 0);
+        }
+    }
+    __syncthreads();
+    const int cnt_nodes = s_cnt;
+    if (a.counters && blockIdx.x == 0 && t == 0) {
+        unsigned long long cols = 0;
+        for (int q = 0; q < cnt_nodes; ++q) cols += (unsigned long long)(a.node_active ? a.node_active[s_list[q]] : a.m);
+        atomicAdd(a.counters + 0, (unsigned long long)cnt_nodes);
+        atomicAdd(a.counters + 1, cols * (unsigned long long)((a.dot_mode == 1 || a.Bvec) ? 3 : 2));
+    }
+
+    for (int blk = b_lo + slot; blk < b_hi; blk += S) {
+        const int r0 = a.blk_start[blk], nrow = a.blk_start[blk + 1] - r0;
+        const int e0 = a.ext_ptr[blk], next = a.ext_ptr[blk + 1] - e0;
+        const int my_hi = r0 + nrow;
+        // ---- once per row block, shared by all nodes: the matrix rows of this lane group in registers (row bounds, then
+        //      the first 16 nonzeros' LDS slot / A / B -- two dependent trips instead of two per row), and the outside-row
+        //      indices of this wave's staging instructions
+        int k0r[FH_LDS_RPG], k1r[FH_LDS_RPG], lcr[FH_LDS_RPG];
+        VT ar[FH_LDS_RPG], br[FH_LDS_RPG];
+#pragma unroll
+        for (int s = 0; s < FH_LDS_RPG; ++s) {
+            const int i = r0 + s * 16 + wave * 4 + g;
+            k0r[s] = i < my_hi ? rowptr[i] : 0;
+            k1r[s] = i < my_hi ? rowptr[i + 1] : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < FH_LDS_RPG; ++s) {
+            const bool in = k0r[s] + l16 < k1r[s];
+            lcr[s] = in ? (int)lcol[k0r[s] + l16] : 0;
+            ar[s] = in ? aval[k0r[s] + l16] : fh_vzero(VT());
+            br[s] = fh_vzero(VT());
+            if (!BIDENT) br[s] = in ? bval[k0r[s] + l16] : fh_vzero(VT());
+        }
+        constexpr int NQ = (FH_SPMM_EXT / 4 + FH_BLOCK / 64 - 1) / (FH_BLOCK / 64);
+        int egrow[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int sl = 4 * (wave + j * (FH_BLOCK / 64)) + g;
+            egrow[j] = sl < next ? a.ext_idx[e0 + sl] : r0;
+        }
+        for (int nq = 0; nq < cnt_nodes; ++nq) {
+            const int node = __builtin_amdgcn_readfirstlane(s_list[nq]);
+            const CT* __restrict__ X = (const CT*)a.X + (size_t)node * a.x_node_stride;
+            CT* __restrict__ Y = (CT*)a.Y + (size_t)node * a.y_node_stride;
+            const CT* __restrict__ Bv = a.Bvec ? (const CT*)a.Bvec + (size_t)node * a.b_node_stride : nullptr;
+            const CT* __restrict__ U = a.U ? (const CT*)a.U + (size_t)node * a.u_node_stride : nullptr;
+            const CT ca = a.coefA[node * LD + c];
+            const CT cb = a.coefB[node * LD + c];
+            __syncthreads();                                  // the previous readers are done with the window
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): every index / metadata load has landed, so the
+                                                              // compiler has no reason to wait between the DMA instructions
+            // ---- stage: own rows into slots [0, nrow), outside rows into [R, R + next).  Every lane issues (a lane
+            //      without a row re-reads row r0 into a slot nobody looks at): the LDS destination of the wave-instruction
+            //      is lane 0's address + 16 * lane, so no lane may drop out.
+            for (int q = wave; q * 4 < nrow; q += FH_BLOCK / 64) {
+                const int sl = 4 * q + g;
+                const int grow = sl < nrow ? r0 + sl : r0;
+                __builtin_amdgcn_global_load_lds((const void*)(X + (size_t)grow * LD + c),
+                                                 (void __attribute__((address_space(3)))*)(lds_x + (size_t)sl * 16 + l16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = wave + j * (FH_BLOCK / 64);
+                if (q * 4 < next) {
+                    const int sl = 4 * q + g;
+                    __builtin_amdgcn_global_load_lds((const void*)(X + (size_t)egrow[j] * LD + c),
+                                                     (void __attribute__((address_space(3)))*)(lds_x + (size_t)(FH_SPMM_R + sl) * 16 + l16), 16, 0, 0);
+                }
+            }
+            __syncthreads();                                  // drains vmcnt(0): the window is complete
+            cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+#pragma nounroll
+            for (int s = 0; s < FH_LDS_RPG; ++s) {
+                const int i = r0 + s * 16 + wave * 4 + g;
+                if (i < my_hi) {
+                    const int k0 = FH_SEL8(k0r, s), k1 = FH_SEL8(k1r, s);
+                    int mylc = FH_SEL8(lcr, s); VT mya = FH_SEL8(ar, s), myb = FH_SEL8(br, s);
+                    CT acc = cmake(0, 0);
+                    const CT xown = lds_x[(size_t)(i - r0) * 16 + l16];
+                    if (BIDENT) acc = cmul(cb, xown);
+                    for (int kb = k0; kb < k1; kb += 16) {
+                        if (kb != k0) {                       // rows longer than 16 nonzeros: load on demand
+                            const int kk = kb + l16;
+                            const bool in = kk < k1;
+                            mylc = in ? (int)lcol[kk] : 0;
+                            mya = in ? aval[kk] : fh_vzero(VT());
+                            myb = fh_vzero(VT());
+                            if (!BIDENT) myb = in ? bval[kk] : fh_vzero(VT());
+                        }
+                        CT mys = cmake(0, 0);
+                        if (a.uniform_coef) {
+                            mys = vmul(mya, ca);
+                            if (!BIDENT) mys = cadd(mys, vmul(myb, cb));
+                        }
+                        const int cnt = min(16, k1 - kb);
+#pragma unroll
+                        for (int q0 = 0; q0 < 16; q0 += 8) {
+                            if (q0 >= cnt) break;
+                            CT xs[8];
+                            int lcq[8];
+                            bool ovf = false;
+                            // all LDS reads of the batch issued without a branch in between (a per-nonzero branch on the
+                            // overflow marker made every read wait for the previous one: 2.3 us per 4-row step)
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                lcq[q] = (q0 + q < cnt) ? fh_bc16(mylc, q0 + q) : (i - r0);
+                                ovf |= lcq[q] == 0xFFFF;
+                                xs[q] = lds_x[(size_t)(lcq[q] == 0xFFFF ? (i - r0) : lcq[q]) * 16 + l16];
+                            }
+                            if (__any(ovf)) {                 // rare: outside rows beyond the kept list come from global memory
+#pragma unroll
+                                for (int q = 0; q < 8; ++q)
+                                    if (lcq[q] == 0xFFFF) xs[q] = X[(size_t)colidx[kb + q0 + q] * LD + c];
+                            }
+                            if (a.uniform_coef) {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) cfma(acc, fh_bc16(mys, q0 + q), xs[q]);
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) {
+                                    CT sc = vmul(fh_bc16(mya, q0 + q), ca);
+                                    if (!BIDENT) sc = cadd(sc, vmul(fh_bc16(myb, q0 + q), cb));
+                                    cfma(acc, sc, xs[q]);
+                                }
+                            }
+                        }
+                    }
+                    if (Bv) acc = csub(fh_ld_nt(Bv + (size_t)i * LD + c), acc);
+                    fh_st_nt(Y + (size_t)i * LD + c, acc);
+                    if (a.dot_mode == 1) {
+                        d1 = cadd(d1, cmulc(fh_ld_nt(U + (size_t)i * LD + c), acc));
+                    } else if (a.dot_mode == 2) {
+                        d1 = cadd(d1, cmulc(acc, xown));
+                        d2.x += cabs2(acc);
+                    } else if (a.dot_mode == 3) {
+                        d2.x += cabs2(acc);
+                    } else if (a.dot_mode == 4) {
+                        d1 = cadd(d1, cmul(xown, acc));
+                    }
+                }
+            }
+            if (a.dot_mode != 0) {
+                // this row block's share of the node's partial sums, added in block order (one owner: deterministic)
+                const size_t pbase = ((size_t)node * nprow + prow) * LD + ct * 16;
+                if (a.dot_mode == 1 || a.dot_mode == 2 || a.dot_mode == 4) {
+                    red[t] = d1;
+                    __syncthreads();
+                    if (t < 16) {
+                        cplx sacc = a.partial1[pbase + t];
+                        for (int k = 0; k < 16; ++k) sacc = cadd(sacc, red[t + 16 * k]);
+                        a.partial1[pbase + t] = sacc;
+                    }
+                    __syncthreads();
+                }
+                if (a.dot_mode == 2 || a.dot_mode == 3) {
+                    red[t] = d2;
+                    __syncthreads();
+                    if (t < 16) {
+                        cplx sacc = a.partial2[pbase + t];
+                        for (int k = 0; k < 16; ++k) sacc = cadd(sacc, red[t + 16 * k]);
+                        a.partial2[pbase + t] = sacc;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
+// grid of the LDS-window kernel: 8 XCD groups x S slots, two workgroups per CU resident
+int fh_spmm_lds_slots(int nblk_rows, int ld) {
+    const int nt = ld / 16, slices = 8 / nt;
+    int per = (nblk_rows + slices - 1) / slices;
+    int S = per < 64 ? per : 64;
+    return S < 1 ? 1 : S;
+}
+
+template <typename VT, int LD>
+static void launch_spmm_lds(const fh_spmm_args& a, bool bident, hipStream_t st) {
+    const size_t dyn = (size_t)FH_LDS_SLOTS * 16 * sizeof(cplx);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)k_spmm_lds<VT, LD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        hipFuncSetAttribute((const void*)k_spmm_lds<VT, LD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_done = true;
+    }
+    dim3 grid(8 * fh_spmm_lds_slots(a.nblk_rows, LD)), block(FH_BLOCK);
+    if (bident) hipLaunchKernelGGL((k_spmm_lds<VT, LD, true>), grid, block, dyn, st, a);
+    else hipLaunchKernelGGL((k_spmm_lds<VT, LD, false>), grid, block, dyn, st, a);
+}
+
 template <typename CT, typename VT, int LD>
 static void launch_spmm_ld(const fh_spmm_args& a, bool bident, int nblk, hipStream_t st) {
     dim3 grid(nblk), block(FH_BLOCK);
@@ -273,6 +548,18 @@ static void launch_spmm_ct(const fh_spmm_args& a, int ld, bool is_complex, bool 
     }
 }
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st) {
+    if (a.prec == 64 && a.lcol) {          // renumbered matrix, complex128 panels: the LDS-window kernel
+        if (is_complex) {
+            if (ld == 16) launch_spmm_lds<cplx, 16>(a, bident, st);
+            else if (ld == 32) launch_spmm_lds<cplx, 32>(a, bident, st);
+            else launch_spmm_lds<cplx, 64>(a, bident, st);
+        } else {
+            if (ld == 16) launch_spmm_lds<double, 16>(a, bident, st);
+            else if (ld == 32) launch_spmm_lds<double, 32>(a, bident, st);
+            else launch_spmm_lds<double, 64>(a, bident, st);
+        }
+        return;
+    }
     if (a.prec == 32) launch_spmm_ct<cplxf>(a, ld, is_complex, bident, nblk, st);
     else launch_spmm_ct<cplx>(a, ld, is_complex, bident, nblk, st);
 }
