@@ -161,3 +161,28 @@ def test_column_mask_keeps_initial_guess(engine):
         assert np.allclose(P[:, c], want, atol=1e-9), c
     lib = engine.lib
     assert lib.feasthip_set_column_mask(engine.h, -1, None) == 2
+
+
+@pytest.mark.parametrize("solver", ["cocg", "bicgstab", "gmres"])
+def test_non_finite_residual_is_never_reported_converged(engine, solver):
+    """A NaN in one right-hand-side column: that column's residual norm is not finite.  `!(NaN > target)` is true, so an
+    unguarded stop test marks it converged (k_fin_rho tested the target before isfinite; the host gather
+    dropped NaN ratios).  The solve must come back with the no-convergence code, the clean columns solved; and the one-shot
+    column mask must not leak into this call (same review)."""
+    import feast_oracle as fo
+    A, B, lam = fo.cfg3_problem(8, 7, 6)
+    N = A.shape[0]
+    engine.set_problem(A, B)
+    engine.set_solver(solver, rtol=1e-10, atol=0.0, maxit=3000, restart=40)
+    engine.set_column_mask([0, 0, 0, 0])             # consumed by contour_apply only: must be ignored here
+    X = np.asfortranarray(fk.seeded_subspace(N, 4).copy())
+    X[3, 2] = np.nan
+    z = 0.45 + 0.3j
+    dY, rc = engine.shifted_solve(z, engine.upload(X), 4)
+    engine.set_column_mask(None)
+    assert rc == 5, rc
+    Y = engine.download(dY, 4)
+    S = z * B.toarray() - A.toarray()
+    for c in (0, 1, 3):
+        ref = np.linalg.solve(S, X[:, c])
+        assert np.abs(Y[:, c] - ref).max() <= 1e-7 * np.abs(ref).max(), (solver, c)
