@@ -171,7 +171,9 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
         int k0n = 0, k1n = 0, k0nn = 0, k1nn = 0;
         if (i_first < row_hi) { k0n = rowptr[i_first]; k1n = rowptr[i_first + 1]; }
         if (i_first + band < row_hi) { k0nn = rowptr[i_first + band]; k1nn = rowptr[i_first + band + 1]; }
-        int ncol = 0; VT na = fh_vzero(VT()), nb = fh_vzero(VT());
+        // (slots past the end of a row hold the row's OWN index and zero values: the gather of such a slot re-reads the
+        //  row's cached line and contributes nothing -- no select in the inner loop)
+        int ncol = i_first; VT na = fh_vzero(VT()), nb = fh_vzero(VT());
         if (i_first < row_hi && k0n + l16 < k1n) {
             ncol = colidx[k0n + l16]; na = aval[k0n + l16];
             if (!BIDENT) nb = bval[k0n + l16];
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
             // prefetch for the next row of this group
             k0n = k0nn; k1n = k1nn;
             if (i + 2 * band < row_hi) { k0nn = rowptr[i + 2 * band]; k1nn = rowptr[i + 2 * band + 1]; }
-            ncol = 0; na = fh_vzero(VT()); nb = fh_vzero(VT());
+            ncol = i + band; na = fh_vzero(VT()); nb = fh_vzero(VT());
             if (i + band < row_hi && k0n + l16 < k1n) {
                 ncol = colidx[k0n + l16]; na = aval[k0n + l16];
                 if (!BIDENT) nb = bval[k0n + l16];
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 if (kb != k0) {                          // rows longer than 16 nonzeros: load on demand
                     const int kk = kb + l16;
                     const bool in = kk < k1;
-                    mycol = in ? colidx[kk] : 0;
+                    mycol = in ? colidx[kk] : i;
                     mya = in ? aval[kk] : fh_vzero(VT());
                     myb = fh_vzero(VT());
                     if (!BIDENT) myb = in ? bval[kk] : fh_vzero(VT());
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                     CT xs[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int j = (q0 + q < cnt) ? fh_bc16(mycol, q0 + q) : i;
+                        const int j = fh_bc16(mycol, q0 + q);
                         xs[q] = X[(size_t)j * LD + c];
                     }
                     if (a.uniform_coef) {
