@@ -138,6 +138,7 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     if (getenv("FH_LU_KB")) h->lu_outer_block = std::max(32, (atoi(getenv("FH_LU_KB")) / 32) * 32);
     h->lu_solve_legacy = getenv("FH_LU_SOLVE_32") != nullptr;
     h->lu_gemm_staged = getenv("FH_LU_GEMM_STAGED") != nullptr;
+    if (getenv("FH_LU_LOOKAHEAD")) h->lu_lookahead = atoi(getenv("FH_LU_LOOKAHEAD"));
     h->sum_mode = getenv("FH_NO_SUM_MODE") ? 0 : 1;
     h->lu_panel_legacy = getenv("FH_LU_PANEL_LEGACY") ? atoi(getenv("FH_LU_PANEL_LEGACY")) : 0;
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
@@ -191,6 +192,9 @@ extern "C" int feasthip_destroy(feasthip_handle h) {
     for (auto& ep : h->pending_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     if (h->h_progress) hipHostFree((void*)h->h_progress);
+    if (h->lu_ev_next) hipEventDestroy(h->lu_ev_next);
+    if (h->lu_ev_rest) hipEventDestroy(h->lu_ev_rest);
+    if (h->side_stream) hipStreamDestroy(h->side_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return 0;

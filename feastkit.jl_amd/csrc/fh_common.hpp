@@ -177,6 +177,10 @@ struct feasthip_ctx {
     int lu_outer_block = 0;       // FH_LU_KB: outer block column of the two-level LU (multiple of 32); 0 = by size (128, 256 from N = 6144)
     int lu_panel_legacy = 0;      // FH_LU_PANEL_LEGACY=1: per-column global-memory panel kernel
     int lu_solve_legacy = 0;      // FH_LU_SOLVE_32=1: 32-column one-launch substitution steps (comparison)
+    int lu_lookahead = 1;         // FH_LU_LOOKAHEAD=0: no overlap of the next block column's panels with the rest of the trailing update
+    hipStream_t side_stream = nullptr;            // second stream of the LU look-ahead (created on first use)
+    int side_reserve = -1;                        // CUs per XCD the side stream's mask leaves to the main stream
+    hipEvent_t lu_ev_next = nullptr, lu_ev_rest = nullptr;
     int lu_gemm_staged = 0;       // FH_LU_GEMM_STAGED=1: trailing update with both panels through LDS (comparison; always for complex64)
 
     // host-mapped progress word written by the device: (chunk tag << 32) | active columns

@@ -1324,6 +1324,54 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     // measured (cfg 2 / cfg 5): at N = 4096 a 256-wide outer block is neutral, at N = 8192 it saves 4-6 % (the k = 256
     // trailing product runs at 52 instead of 46 TFLOP/s and outweighs the longer k = 32 in-block updates)
     const int KB = h->lu_outer_block > 0 ? h->lu_outer_block : (N >= 6144 ? 256 : 128);
+    // Look-ahead: the panels of a block column run one 1024-thread workgroup per matrix (8 or 24 of 256 CUs), so the
+    // trailing update of block column b is split by columns -- the NEXT block column [Kend, Kend2) is updated on the
+    // main stream, the REST [Kend2, N) on a side stream -- and the panels / in-block products of block column b+1
+    // overlap the rest.  Hazards: the rest reads the L columns [K0, Kend) and the pivots of block b and writes only
+    // columns >= Kend2; block column b+1 writes only [Kend, Kend2) and its own pivots; its interchanges on the other
+    // columns (which touch both) wait for the rest.  Same operations on every element, so the factors are bit-identical.
+    const bool lookahead = h->lu_lookahead != 0 && N > 2 * KB;
+    const hipStream_t main_s = h->stream;
+    // CUs per XCD left to the main stream: one per panel workgroup the XCD receives (workgroups go round-robin over XCDs)
+    const int reserve = getenv("FH_LU_RESERVE") ? atoi(getenv("FH_LU_RESERVE")) : std::min(4, (nf + 7) / 8);
+    if (lookahead && (!h->side_stream || h->side_reserve != reserve)) {
+        if (h->side_stream) {
+            FH_CHECK(hipStreamSynchronize(h->side_stream));
+            FH_CHECK(hipStreamDestroy(h->side_stream));
+            h->side_stream = nullptr;
+        }
+        // A panel workgroup (1024 threads x 128 VGPRs) needs a completely empty CU, and the rest update refills every CU
+        // as soon as a tile retires, so on a plain (even low-priority) side stream the panels starved until the tail of
+        // the update (measured: 676 ms of panel time instead of 123).  The side stream is therefore created with a CU mask
+        // that leaves `reserve` CUs per XCD to the main stream.  The reserved set {i : i mod 32 == (i / 32) mod 8 + 8 m,
+        // m < reserve} has `reserve` members in every XCD both for an interleaved (XCD = i mod 8, what the kernel driver
+        // uses on multi-XCD parts) and a blocked (XCD = i / 32) numbering of the mask bits.
+        hipDeviceProp_t prop;
+        int dev = 0;
+        FH_CHECK(hipGetDevice(&dev));
+        FH_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i) {
+            bool reserved = false;
+            for (int m = 0; m < reserve; ++m) reserved |= (i % 32) == ((i / 32) % 8 + 8 * m);
+            if (!reserved) mask[i / 32] |= 1u << (i % 32);
+        }
+        if (reserve > 0) FH_CHECK(hipExtStreamCreateWithCUMask(&h->side_stream, (uint32_t)mask.size(), mask.data()));
+        else {
+            int prio_lo = 0, prio_hi = 0;
+            FH_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            FH_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
+        }
+        h->side_reserve = reserve;
+        if (!h->lu_ev_next) {
+            FH_CHECK(hipEventCreateWithFlags(&h->lu_ev_next, hipEventDisableTiming));
+            FH_CHECK(hipEventCreateWithFlags(&h->lu_ev_rest, hipEventDisableTiming));
+        }
+    }
+    // measured (cfg 2 sweeps): no look-ahead 84 ms, plain side stream 79, plain + 4 chunks 74, CU mask 68, mask + chunks 72
+    const int lu_chunks = getenv("FH_LU_CHUNKS") ? std::max(1, atoi(getenv("FH_LU_CHUNKS"))) : (reserve > 0 ? 1 : KB / LU_NB);
+    bool rest_pending = false;
     for (int K0 = 0; K0 < N; K0 += KB) {
         const int Kend = std::min(N, K0 + KB);
         for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
@@ -1347,16 +1395,38 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
                 gemm(k0, LU_NB, k0 + nb, N, k0 + nb, Kend, "lu_gemm_in");
             }
         }
-        // the block column's interchanges on everything outside it
-        laswp(K0, Kend - K0, 0, K0, Kend, N);
-        if (Kend < N) {               // Kend - K0 == KB here
+        if (rest_pending) {           // the previous block's rest update: read the L columns the next call interchanges
+            FH_CHECK(hipStreamWaitEvent(main_s, h->lu_ev_rest, 0));
+            rest_pending = false;
+        }
+        // the block column's interchanges, U block row and trailing update on columns [a, b) right of it
+        auto right_of_block = [&](int a, int b, int chunks) {
+            if (Kend >= N || a >= b) return;   // Kend - K0 == KB from here
             for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
-                trsm(k0, Kend, N);
-                gemm(k0, LU_NB, k0 + LU_NB, Kend, Kend, N, "lu_gemm_in");
+                trsm(k0, a, b);
+                gemm(k0, LU_NB, k0 + LU_NB, Kend, a, b, "lu_gemm_in");
             }
-            gemm(K0, KB, Kend, N, Kend, N, "lu_gemm");
+            // in column chunks when it runs beside the next block column: a panel workgroup needs an empty CU and gets
+            // one when a chunk drains (an in-order stream starts the next chunk only after the last tile of this one)
+            const int step = std::max(512, (((b - a + chunks - 1) / chunks + 511) / 512) * 512);   // whole 8 x 64 super-tile columns
+            for (int c = a; c < b; c += step) gemm(K0, KB, Kend, N, c, std::min(b, c + step), "lu_gemm");
+        };
+        const int Kend2 = lookahead ? std::min(N, Kend + KB) : N;
+        laswp(K0, Kend - K0, 0, K0, Kend, Kend2);
+        right_of_block(Kend, Kend2, 1);
+        if (Kend2 < N) {
+            FH_CHECK(hipEventRecord(h->lu_ev_next, main_s));
+            FH_CHECK(hipStreamWaitEvent(h->side_stream, h->lu_ev_next, 0));
+            h->stream = h->side_stream;       // the launch helpers and the profiler follow h->stream
+            laswp(K0, Kend - K0, 0, 0, Kend2, N);
+            right_of_block(Kend2, N, lu_chunks);
+            const hipError_t er = hipEventRecord(h->lu_ev_rest, h->side_stream);
+            h->stream = main_s;
+            FH_CHECK(er);
+            rest_pending = true;
         }
     }
+    if (rest_pending) FH_CHECK(hipStreamWaitEvent(main_s, h->lu_ev_rest, 0));
     fh_prof_begin(h, "lu_invert");
     hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, N);
     {   // 128 x 128 inverses from the 32-block inverses: the in-block substitution applied to the identity
