@@ -393,6 +393,14 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(T* const* LUs, in
     }
 }
 
+// broadcast of one lane's value with a wave-uniform lane index: v_readlane (scalar path, a few cycles) instead of the
+// ds_bpermute a generic __shfl costs (LDS round trip, on the dependent chain of the substitutions below)
+__device__ inline double lu_readlane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline float lu_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
 // Register-resident panel factorisation.  One workgroup (1024 threads) per matrix; thread t
 // owns rows k0 + t + 1024 r (r < R) of the panel.  The nb panel columns are processed
 // left-looking in sub-panels of W columns (R*W = 16 complex values = 64 VGPRs per thread):
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
             if (wave < wact) {
                 T x = lane < pc ? Us[lane][wave] : LU_MK(0, 0);
                 for (int i = 0; i + 1 < pc; ++i) {
-                    const T xi = LU_MK(__shfl(x.x, i), __shfl(x.y, i));
+                    const T xi = LU_MK(lu_readlane(x.x, i), lu_readlane(x.y, i));
                     if (lane > i && lane < pc) x = csub(x, cmul(Lsm[lane][i], xi));
                 }
                 if (lane < pc) {
@@ -575,6 +583,24 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                 if (rows[r] >= c0 && rows[r] < N && w < wact) A[(size_t)(c0 + w) * N + rows[r]] = a[r][w];
         __syncthreads();
     }
+    // ---- inverse of the unit-lower diagonal block, for the U block row (k_lu_trsm_mul): column c of L11^-1 by forward
+    // substitution on e_c, one wave per column, lane = row, the solved component broadcast by shuffle
+    if (nb == LU_NB) {
+        for (int e = t; e < LU_NB * LU_NB; e += LU_PANEL_THREADS) {
+            const int i = e % LU_NB, j = e / LU_NB;
+            Lsm[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
+        }
+        __syncthreads();
+        T* inv = A + (size_t)N * N + (size_t)(k0 / LU_NB) * 2 * LU_NB * LU_NB;
+        for (int c = wave; c < LU_NB; c += LU_PANEL_THREADS / 64) {
+            T x = LU_MK(lane == c ? 1.0 : 0.0, 0.0);
+            for (int i = c; i + 1 < LU_NB; ++i) {
+                const T xi = LU_MK(lu_readlane(x.x, i), lu_readlane(x.y, i));
+                if (lane > i && lane < LU_NB) x = csub(x, cmul(Lsm[lane][i], xi));
+            }
+            if (lane < LU_NB) inv[c * LU_NB + lane] = x;
+        }
+    }
 }
 
 // apply the row interchanges piv[p0 .. p0+np) to the columns [a0,a1) and [b0,b1)
@@ -619,6 +645,29 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(T* const* LUs, int N, int 
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) A[(size_t)c * N + k0 + i] = x[i];
+}
+
+// U block row as a product with the inverse the panel kernel left behind the factor:
+// A[k0:k0+NB, c] = L11^-1 A[k0:k0+NB, c].  One thread per ENTRY (NB rows x 8 columns per workgroup): 32 independent
+// multiply-adds instead of the substitution's 31 dependent steps per thread, coalesced 512 B column segments.
+template <int NB, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm_mul(T* const* LUs, int N, int k0, int c0, int c1) {
+    static_assert(FH_BLOCK % NB == 0, "rows x columns tiling");
+    constexpr int CW = FH_BLOCK / NB;
+    T* A = LUs[blockIdx.y];
+    const T* inv = A + (size_t)N * N + (size_t)(k0 / NB) * 2 * NB * NB;
+    __shared__ T Li[NB * NB];          // column-major: Li[j * NB + i], lanes read consecutive i
+    __shared__ T a[CW][NB];
+    const int t = threadIdx.x, i = t % NB, cc = t / NB;
+    for (int e = t; e < NB * NB; e += FH_BLOCK) Li[e] = inv[e];
+    const int c = c0 + blockIdx.x * CW + cc;
+    if (c < c1) a[cc][i] = A[(size_t)c * N + k0 + i];
+    __syncthreads();
+    if (c >= c1) return;
+    T s = LU_MK(0, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cfma(s, Li[j * NB + i], a[cc][j]);
+    A[(size_t)c * N + k0 + i] = s;
 }
 
 // A[r0:r1, c0:c1] -= A[r0:r1, k0:k0+kd] * A[k0:k0+kd, c0:c1]  (kd a multiple of KC = 32) on
@@ -1302,9 +1351,16 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         hipLaunchKernelGGL((k_lu_laswp<T>), dim3((ncols + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, dpvs, N, p0, np, a0, a1, b0, b1);
         fh_prof_end(h);
     };
+    // panels factorised by k_lu_panel_reg leave L11^-1 behind the factor (full 32-column panels only)
+    static const bool trsm_subst = getenv("FH_LU_TRSM_SUBST") != nullptr;
+    auto panel_in_registers = [&](int k0) { return !h->lu_panel_legacy && N - k0 <= 16 * LU_PANEL_THREADS; };
     auto trsm = [&](int k0, int c0, int c1) {
+        if (c1 <= c0) return;
         fh_prof_begin(h, "lu_trsm");
-        hipLaunchKernelGGL((k_lu_trsm<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
+        if (!trsm_subst && panel_in_registers(k0) && k0 + LU_NB <= N)
+            hipLaunchKernelGGL((k_lu_trsm_mul<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK / LU_NB - 1) / (FH_BLOCK / LU_NB), nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
+        else
+            hipLaunchKernelGGL((k_lu_trsm<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
         fh_prof_end(h);
     };
     auto gemm = [&](int k0, int kd, int r0, int r1, int c0, int c1, const char* cls) {
@@ -1380,7 +1436,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
             {
                 const int nrows = N - k0;
                 const dim3 g(nf), b(LU_PANEL_THREADS);
-                if (h->lu_panel_legacy || nrows > 16 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                if (!panel_in_registers(k0)) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
                 else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
                 else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
                 else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
