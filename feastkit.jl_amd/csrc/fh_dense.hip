@@ -1352,7 +1352,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         fh_prof_end(h);
     };
     // panels factorised by k_lu_panel_reg leave L11^-1 behind the factor (full 32-column panels only)
-    static const bool trsm_subst = getenv("FH_LU_TRSM_SUBST") != nullptr;
+    const bool trsm_subst = getenv("FH_LU_TRSM_SUBST") != nullptr;     // comparison: in-place substitution
     auto panel_in_registers = [&](int k0) { return !h->lu_panel_legacy && N - k0 <= 16 * LU_PANEL_THREADS; };
     auto trsm = [&](int k0, int c0, int c1) {
         if (c1 <= c0) return;

@@ -254,6 +254,61 @@ def test_dense_lu_block_widths(kb, legacy_solve, prec, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", [64, 32])
+def test_dense_lu_lookahead_is_bit_identical(prec, monkeypatch):
+    """The look-ahead (next block column's panels beside the rest of the trailing update, side stream with a CU mask,
+    a plain low-priority stream, or a chunked rest update) reorders launches, not arithmetic: the solution of a shifted
+    system must not change in a single bit against the serial order.  N = 1500 gives 12 outer blocks of 128."""
+    import feastkit_jl_amd as fk
+    N, m = 1500, 24
+    rng = np.random.default_rng(15)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    z = 0.1 + 0.3j
+    X = rand_block(N, m, 11)
+    out = {}
+    for name, env in (("serial", {"FH_LU_LOOKAHEAD": "0"}), ("mask", {}), ("mask2", {"FH_LU_RESERVE": "2"}),
+                      ("plain", {"FH_LU_RESERVE": "0", "FH_LU_CHUNKS": "1"}), ("chunks", {"FH_LU_RESERVE": "0"})):
+        for k in ("FH_LU_LOOKAHEAD", "FH_LU_RESERVE", "FH_LU_CHUNKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = fk.HipEngine(0)
+        eng.set_problem(A, None)
+        eng.set_solver("direct", factor_precision=prec)
+        dY, rc = eng.shifted_solve(z, eng.upload(X), m)
+        assert rc == 0
+        out[name] = eng.download(dY).copy()
+        eng.close()
+    Sm = z * np.eye(N) - A
+    assert (np.linalg.norm(Sm @ out["serial"] - X, axis=0) / np.linalg.norm(X, axis=0)).max() < 1e-10
+    for name in ("mask", "mask2", "plain", "chunks"):
+        assert np.array_equal(out[name], out["serial"]), name
+
+
+def test_dense_lu_trsm_product_matches_substitution(monkeypatch):
+    """U block row by the product with L11^-1 (default) against the in-place substitution (FH_LU_TRSM_SUBST=1): same
+    factorisation up to rounding, both against LAPACK."""
+    import feastkit_jl_amd as fk
+    N, m = 700, 16
+    rng = np.random.default_rng(16)
+    A = rng.standard_normal((N, N)) + 1j * rng.standard_normal((N, N))
+    z = -0.2 + 0.5j
+    X = rand_block(N, m, 12)
+    Sm = z * np.eye(N) - A
+    ref = sla.lu_solve(sla.lu_factor(Sm), X)
+    for subst in (False, True):
+        if subst:
+            monkeypatch.setenv("FH_LU_TRSM_SUBST", "1")
+        eng = fk.HipEngine(0)
+        eng.set_problem(A, None)
+        eng.set_solver("direct")
+        dY, rc = eng.shifted_solve(z, eng.upload(X), m)
+        assert rc == 0
+        Y = eng.download(dY)
+        eng.close()
+        assert np.abs(Y - ref).max() <= 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("prec", [64, 32])
 def test_dense_lu_tall_panels(engine, prec):
     """N > 8192: the first panels hold more than 8 x 1024 rows and take the 16-rows-per-thread panel kernel
     (k_lu_panel_reg<16,1>) and the 256-wide outer block; checked through the residual of a shifted solve."""
