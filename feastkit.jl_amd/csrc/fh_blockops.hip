@@ -221,14 +221,32 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gram_mfma(const cplx* __restrict__
 #pragma unroll
             for (int t = 0; t < NS; ++t) y[u][t] = in ? Y[(size_t)i * LD + t * 16 + lc] : cmake(0, 0);
         }
+        // Panels without imaginary parts (the real projection of a real pencil: Q_proj, its orthonormal basis, A Q, the
+        // Ritz vectors) need one of the four real products; the skipped ones would add exact zeros, so the result is
+        // bit-identical.  Decided per step from the data the wave just loaded, not from a mode flag.
+        bool has_imag = false;
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
+            has_imag |= x[u].y != 0.0;
 #pragma unroll
-            for (int t = 0; t < NS; ++t) {
-                rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].x, rr[t], 0, 0, 0);
-                ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, y[u][t].y, ii[t], 0, 0, 0);
-                ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].y, ri[t], 0, 0, 0);
-                ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, y[u][t].x, ir[t], 0, 0, 0);
+            for (int t = 0; t < NS; ++t) has_imag |= y[u][t].y != 0.0;
+        }
+        if (__any(has_imag)) {
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].x, rr[t], 0, 0, 0);
+                    ii[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, y[u][t].y, ii[t], 0, 0, 0);
+                    ri[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].y, ri[t], 0, 0, 0);
+                    ir[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].y, y[u][t].x, ir[t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+#pragma unroll
+                for (int t = 0; t < NS; ++t) rr[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u].x, y[u][t].x, rr[t], 0, 0, 0);
             }
         }
     }
@@ -338,20 +356,33 @@ __global__ __launch_bounds__(FH_BLOCK) void k_small_matmul_mfma(const cplx* __re
     cplx vB[KS];
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) vB[kk] = V[(size_t)(16 * ct + lr) * LD + 4 * kk + lk];     // V[k + LD*c]
+    // real V (real reduced eigenvectors, real R^-1) and real rows of Q: one real product instead of four, bit-identical
+    bool v_imag = false;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) v_imag |= vB[kk].y != 0.0;
+    v_imag = __any(v_imag);
     for (int i0 = blockIdx.x * RB; i0 < N; i0 += gridDim.x * RB) {
+        int q_imag = 0;
         for (int e = t; e < RB * LD; e += FH_BLOCK) {
             const int r = e / LD, c = e % LD;
-            Qs[r][c] = (i0 + r < N) ? Q[(size_t)(i0 + r) * LD + c] : cmake(0, 0);
+            const cplx q = (i0 + r < N) ? Q[(size_t)(i0 + r) * LD + c] : cmake(0, 0);
+            q_imag |= q.y != 0.0;
+            Qs[r][c] = q;
         }
-        __syncthreads();
+        q_imag = __syncthreads_or(q_imag);          // the barrier the tile needs anyway
         v4d re = {0, 0, 0, 0}, im = {0, 0, 0, 0};
+        if (v_imag || q_imag) {
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const cplx a = Qs[16 * sb + lr][4 * kk + lk];
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vB[kk].x, re, 0, 0, 0);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, vB[kk].y, re, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vB[kk].y, im, 0, 0, 0);
-            im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vB[kk].x, im, 0, 0, 0);
+            for (int kk = 0; kk < KS; ++kk) {
+                const cplx a = Qs[16 * sb + lr][4 * kk + lk];
+                re = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vB[kk].x, re, 0, 0, 0);
+                re = __builtin_amdgcn_mfma_f64_16x16x4f64(-a.y, vB[kk].y, re, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, vB[kk].y, im, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, vB[kk].x, im, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) re = __builtin_amdgcn_mfma_f64_16x16x4f64(Qs[16 * sb + lr][4 * kk + lk].x, vB[kk].x, re, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -29,7 +29,8 @@ import time
 import numpy as np
 import scipy.linalg as sla
 
-from .contour import balanced_contour_points, cost_balanced_contour_points, distribute_contour_points, feast_contour, feast_gcontour, feast_inside_gcontour
+from .contour import (balanced_contour_points, cost_balanced_contour_points, distribute_contour_points, feast_contour, feast_gcontour,
+                      feast_inside_gcontour, split_balanced_assignment)
 from .parameters import check_feast_srci_input, feast_tolerance, feastdefault
 from .types import FeastError, FeastResult
 
@@ -183,7 +184,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         raise ValueError("column_groups must divide the world size and needs an iterative solver")
     node_groups = world // column_groups
     node_rank, col_rank = rank // column_groups, rank % column_groups
-    if node_assignment == "balanced" and node_groups > 1:
+    if (node_assignment == "balanced" or callable(node_assignment)) and node_groups > 1:
         nodes_here = balanced_contour_points(len(Zne), node_groups)[node_rank]
         engine.set_node_list(nodes_here)
         count = len(nodes_here)
@@ -193,13 +194,19 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         engine.set_node_range(first, count)
         local_nodes = list(range(first, first + count))
 
+    # this rank's column group (my_cg of my_cgs): fixed by the (node groups) x (column groups) grid, or re-derived every
+    # loop by split_balanced_assignment, which splits only the heaviest nodes by columns
+    my_cg, my_cgs = col_rank, column_groups
+    split_layout = (callable(node_assignment) or node_assignment == "balanced") and column_groups == 1 and world > 1 and iterative
+    node_parts = {}                                  # node -> column groups it was swept in (its iteration count arrives summed)
+
     def column_block(ncols):
         """[c0, c1) of this rank's column group: blocks in multiples of 16, remainder to the last."""
-        if column_groups == 1:
+        if my_cgs == 1:
             return 0, ncols
-        per = max(16, -(-ncols // column_groups // 16) * 16) if ncols >= 16 * column_groups else -(-ncols // column_groups)
-        c0 = min(ncols, col_rank * per)
-        c1 = ncols if col_rank == column_groups - 1 else min(ncols, c0 + per)
+        per = max(16, -(-ncols // my_cgs // 16) * 16) if ncols >= 16 * my_cgs else -(-ncols // my_cgs)
+        c0 = min(ncols, my_cg * per)
+        c1 = ncols if my_cg == my_cgs - 1 else min(ncols, c0 + per)
         return c0, c1
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
                       restart=solver_restart, cache_factors=True)
@@ -252,13 +259,13 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
             col_mask = np.array([1 if Emin <= lam_guess[c] <= Emax else 0 for c in range(active)], dtype=np.int32)
         if hasattr(engine, "set_column_mask"):
             engine.set_column_mask(col_mask)                    # one-shot: consumed by the sweep below
-        if column_groups > 1:
+        if my_cgs > 1:
             c0, c1 = column_block(active)
             engine.set_column_block(c0, c1 - c0)
         # one call = this rank's (nodes x column block) sweep + the packed all-reduce inside the C ABI:
         # dP and status come back summed over all ranks (status indexed by contour node when world > 1)
         dP, status, st = engine.contour_apply(dQ, active, lam_guess)
-        if column_groups > 1:
+        if my_cgs > 1:
             engine.set_column_block(0, -1)
         ph["apply"] += tick() - t_
         stats["krylov_iterations"] += st.get("krylov_iterations", 0)
@@ -269,7 +276,20 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
             stats["node_iterations"].append([int(v) for v in engine.last_node_iterations(count)])
             stats["node_lists"].append([int(v) for v in local_nodes])
         local_fail = int(np.max(status)) if (world > 1 or count > 0) else 0
-        if (node_assignment == "balanced" and node_groups > 1 and iterative and hasattr(engine, "last_global_node_iterations")
+        if split_layout and loop_idx >= 1 and hasattr(engine, "last_global_node_iterations"):
+            # node-only layout asked for: re-derive it from the measured iteration counts and let the heaviest nodes be
+            # split by columns over several ranks when that lowers the largest share (contour.split_balanced_assignment);
+            # the counts arrived in the tail of the packed all-reduce, summed over the ranks that swept a node
+            costs = [float(v) / node_parts.get(e, 1) for e, v in enumerate(engine.last_global_node_iterations())]
+            layout = node_assignment(costs, world) if callable(node_assignment) else split_balanced_assignment(costs, world, ncols=active)
+            nodes_here, my_cg, my_cgs = layout[rank]
+            node_parts = {e: k for nodes, _g, k in layout for e in nodes}
+            stats["layout"] = [(list(map(int, nodes)), int(g), int(k)) for nodes, g, k in layout]
+            if list(nodes_here) != list(local_nodes):
+                engine.set_node_list(nodes_here)
+                count, local_nodes = len(nodes_here), list(nodes_here)
+                stats["local_nodes"] = [int(v) for v in local_nodes]
+        elif (node_assignment == "balanced" and node_groups > 1 and iterative and hasattr(engine, "last_global_node_iterations")
                 and loop_idx >= 1):
             # re-balance the node groups from the iteration counts the sweep just measured (they arrived in the tail of the
             # packed all-reduce and are identical on every rank): the slow near-axis nodes no longer share a group by accident
