@@ -266,14 +266,20 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gram_mfma(const cplx* __restrict__
     }
 }
 
+// Sum of the per-(block, subset) partial tiles in a fixed order, two stages: FH_GRAM_GROUPS groups of consecutive slots
+// are summed side by side (grid.y), then the group sums in group order.  (One stage with a thread per entry walked
+// 256 slots of 131 KB stride from 16 workgroups: about half of the whole Gram product's time.)
+#define FH_GRAM_GROUPS 16
 template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_gram_reduce(const cplx* __restrict__ partial, int nslots,
-                                                           int bilinear, cplx* __restrict__ G) {
+__global__ __launch_bounds__(FH_BLOCK) void k_gram_reduce_groups(const cplx* __restrict__ partial, int nslots,
+                                                                  cplx* __restrict__ gsum) {
     const int e = blockIdx.x * FH_BLOCK + threadIdx.x;
     if (e >= LD * LD) return;
+    const int per = (nslots + FH_GRAM_GROUPS - 1) / FH_GRAM_GROUPS;
+    const int s0 = blockIdx.y * per, s1 = min(nslots, s0 + per);
     double rr = 0, ii = 0, ri = 0, ir = 0;
-    int s = 0;
-    for (; s + 8 <= nslots; s += 8) {            // eight slots' loads in flight, added in slot order
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {            // eight slots' loads in flight, added in slot order
         cplx a[8], b[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -283,34 +289,50 @@ __global__ __launch_bounds__(FH_BLOCK) void k_gram_reduce(const cplx* __restrict
 #pragma unroll
         for (int q = 0; q < 8; ++q) { rr += a[q].x; ii += a[q].y; ri += b[q].x; ir += b[q].y; }
     }
-    for (; s < nslots; ++s) {
+    for (; s < s1; ++s) {
         const cplx* p = partial + (size_t)s * LD * LD * 2 + (size_t)e * 2;
         cplx a = p[0], b = p[1];
         rr += a.x; ii += a.y; ri += b.x; ir += b.y;
     }
+    cplx* o = gsum + ((size_t)blockIdx.y * LD * LD + e) * 2;
+    o[0] = cmake(rr, ii);
+    o[1] = cmake(ri, ir);
+}
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_gram_reduce(const cplx* __restrict__ gsum, int bilinear, cplx* __restrict__ G) {
+    const int e = blockIdx.x * FH_BLOCK + threadIdx.x;
+    if (e >= LD * LD) return;
+    cplx a[FH_GRAM_GROUPS], b[FH_GRAM_GROUPS];
+#pragma unroll
+    for (int g = 0; g < FH_GRAM_GROUPS; ++g) {
+        const cplx* p = gsum + ((size_t)g * LD * LD + e) * 2;
+        a[g] = p[0]; b[g] = p[1];
+    }
+    double rr = 0, ii = 0, ri = 0, ir = 0;
+#pragma unroll
+    for (int g = 0; g < FH_GRAM_GROUPS; ++g) { rr += a[g].x; ii += a[g].y; ri += b[g].x; ir += b[g].y; }
     G[e] = bilinear ? cmake(rr - ii, ri + ir) : cmake(rr + ii, ri - ir);
 }
 
 size_t fh_gram_work_elems(int ld) {
     int sub = 4 / (ld / 16);
-    return (size_t)FH_GRAM_BLOCKS * sub * ld * ld * 2;
+    return (size_t)FH_GRAM_BLOCKS * sub * ld * ld * 2 + (size_t)FH_GRAM_GROUPS * ld * ld * 2;
 }
 
+template <int LD>
+static void gram_launch(const cplx* X, const cplx* Y, int N, int bilinear, cplx* work, cplx* G, hipStream_t st) {
+    constexpr int sub = 4 / (LD / 16), nslots = FH_GRAM_BLOCKS * sub;
+    const int nred = (LD * LD + FH_BLOCK - 1) / FH_BLOCK;
+    cplx* gsum = work + (size_t)nslots * LD * LD * 2;
+    hipLaunchKernelGGL((k_gram_mfma<LD>), dim3(FH_GRAM_BLOCKS), dim3(FH_BLOCK), 0, st, X, Y, N, work);
+    hipLaunchKernelGGL((k_gram_reduce_groups<LD>), dim3(nred, FH_GRAM_GROUPS), dim3(FH_BLOCK), 0, st, work, nslots, gsum);
+    hipLaunchKernelGGL((k_gram_reduce<LD>), dim3(nred), dim3(FH_BLOCK), 0, st, gsum, bilinear, G);
+}
 void fh_launch_gram(const cplx* X, const cplx* Y, int N, int ld, int bilinear, cplx* work, cplx* G,
                     hipStream_t st) {
-    int nblk = FH_GRAM_BLOCKS;
-    int sub = 4 / (ld / 16);
-    int nred = (ld * ld + FH_BLOCK - 1) / FH_BLOCK;
-    if (ld == 16) {
-        hipLaunchKernelGGL((k_gram_mfma<16>), dim3(nblk), dim3(FH_BLOCK), 0, st, X, Y, N, work);
-        hipLaunchKernelGGL((k_gram_reduce<16>), dim3(nred), dim3(FH_BLOCK), 0, st, work, nblk * sub, bilinear, G);
-    } else if (ld == 32) {
-        hipLaunchKernelGGL((k_gram_mfma<32>), dim3(nblk), dim3(FH_BLOCK), 0, st, X, Y, N, work);
-        hipLaunchKernelGGL((k_gram_reduce<32>), dim3(nred), dim3(FH_BLOCK), 0, st, work, nblk * sub, bilinear, G);
-    } else {
-        hipLaunchKernelGGL((k_gram_mfma<64>), dim3(nblk), dim3(FH_BLOCK), 0, st, X, Y, N, work);
-        hipLaunchKernelGGL((k_gram_reduce<64>), dim3(nred), dim3(FH_BLOCK), 0, st, work, nblk * sub, bilinear, G);
-    }
+    if (ld == 16) gram_launch<16>(X, Y, N, bilinear, work, G, st);
+    else if (ld == 32) gram_launch<32>(X, Y, N, bilinear, work, G, st);
+    else gram_launch<64>(X, Y, N, bilinear, work, G, st);
 }
 
 // ---------------------------------------------------------------------------------------
