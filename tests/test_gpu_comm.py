@@ -245,6 +245,61 @@ def test_node_groups_rebalance_between_loops(engine, tmp_path):
     assert abs(last0 - last1) <= 0.35 * (last0 + last1)
 
 
+SPLIT = r'''
+import os, sys, time, json, faulthandler
+faulthandler.dump_traceback_later(300, exit=True)
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np
+import feast_oracle as fo, feastkit_jl_amd as fk
+rank, world, out = int(sys.argv[1]), int(sys.argv[2]), r"{out}"
+eng = fk.HipEngine(0)
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    open(uidf + ".tmp", "wb").write(eng.comm_unique_id()); os.rename(uidf + ".tmp", uidf)
+else:
+    t0 = time.time()
+    while not os.path.exists(uidf):
+        time.sleep(0.01); assert time.time() - t0 < 120
+eng.comm_init(world, rank, open(uidf, "rb").read(), "shm")
+A, B, lam = fo.cfg3_problem(16, 12, 10)
+def layout(costs, world):          # the heaviest node's columns over ranks 0 and 1, every other node on rank 2
+    heavy = [int(np.argmax(costs))]
+    return [(heavy, 0, 2), (heavy, 1, 2), ([e for e in range(len(costs)) if e not in heavy], 0, 1)]
+fpm = fk.feastinit(); fpm[2], fpm[4], fpm[18] = 16, 40, 1500
+r = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 48, fpm, solver="cocg", warm_start=True, inner_rtol=3e-2, solver_maxiter=60,
+                           node_assignment=layout, column_groups=1, real_projection=True)
+json.dump({{"info": r.info, "M": r.M, "eps": r.epsout, "lam": list(np.sort(r.lambda_)), "lists": r.stats["node_lists"],
+           "layout": r.stats.get("layout")}}, open(os.path.join(out, "s%d.json" % rank), "w"))
+eng.barrier(); eng.comm_destroy(); eng.close()
+'''
+
+
+def test_heaviest_node_split_by_columns_over_two_ranks(engine, tmp_path):
+    """Three ranks on one card with a layout callable: the slowest contour node's right-hand-side columns go to ranks 0
+    and 1 (blocks [0, 32) and [32, 48)), the other 15 nodes to rank 2.  Every (node, column) pair is swept exactly once,
+    so the packed reduce gives the single-rank Q_proj and the converged eigenvalues are the closed-form ones."""
+    import json
+    script = tmp_path / "split.py"
+    script.write_text(SPLIT.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FEASTHIP_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(3)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    b = [json.load(open(tmp_path / f"s{r}.json")) for r in range(3)]
+    A, B, lam = fo.cfg3_problem(16, 12, 10)
+    inside = lam[(lam >= 0) & (lam <= 0.42)]
+    for x in b:
+        assert x["info"] == 0 and x["M"] == len(inside) and x["eps"] <= 1e-12
+        assert np.allclose(x["lam"], inside, atol=1e-10)
+    assert b[0]["lam"] == b[1]["lam"] == b[2]["lam"]
+    lay = b[0]["layout"]
+    assert lay == b[1]["layout"] == b[2]["layout"] and lay[0][0] == lay[1][0] and len(lay[0][0]) == 1
+    assert [lay[0][1:], lay[1][1:], lay[2][1:]] == [[0, 2], [1, 2], [0, 1]]
+    assert sorted(lay[0][0] + lay[2][0]) == list(range(16))
+    assert b[0]["lists"][-1] == b[1]["lists"][-1] == lay[0][0] and b[2]["lists"][-1] == lay[2][0]
+
+
 CFG5 = r'''
 import os, sys, time, faulthandler
 faulthandler.dump_traceback_later(300, exit=True)

@@ -434,3 +434,33 @@ def test_cost_balanced_contour_points():
     assert sorted(sum(g3, [])) == [0, 1, 2] and sum(1 for g in g3 if g) == 3
     g1 = fk.cost_balanced_contour_points([0, 0, 0, 0], 2)
     assert sorted(sum(g1, [])) == [0, 1, 2, 3] and all(len(g) == 2 for g in g1)
+
+
+def test_split_balanced_assignment_covers_every_node_column_pair_once():
+    """The heaviest nodes may be split by columns over k ranks; whatever the costs, every (node, column group) pair has
+    exactly one owner, the layout is deterministic, and the largest share never exceeds the node-only LPT share."""
+    from feastkit_jl_amd.contour import cost_balanced_contour_points, split_balanced_assignment
+    cfg3 = [170, 128, 91, 76, 59, 52, 49, 49, 49, 49, 56, 59, 78, 101, 165, 399]        # measured node-iterations per step
+    rng = np.random.default_rng(5)
+    cases = [cfg3, [1] * 16, [1000] + [1] * 15, list(rng.integers(1, 500, 16)), list(rng.integers(1, 50, 7))]
+    for costs in cases:
+        for W in (1, 2, 3, 4, 6, 8):
+            if W > len(costs):
+                continue
+            lay = split_balanced_assignment(costs, W)
+            assert lay == split_balanced_assignment(list(costs), W) and len(lay) == W
+            owners = {}
+            for nodes, g, k in lay:
+                assert 0 <= g < k and k in (1, 2, 4) and len(nodes) >= 1
+                for e in nodes:
+                    owners.setdefault(e, []).append((g, k))
+            assert sorted(owners) == list(range(len(costs)))
+            for e, parts in owners.items():
+                k = parts[0][1]
+                assert sorted(parts) == [(g, k) for g in range(k)]
+            share = max(sum(costs[e] for e in nodes) / k for nodes, g, k in lay)
+            base = max(sum(costs[e] for e in nodes) for nodes in cost_balanced_contour_points(costs, W))
+            assert share <= base + 1e-9
+    lay8 = split_balanced_assignment(cfg3, 8)
+    assert lay8[0] == ([15], 0, 2) and lay8[1] == ([15], 1, 2)                          # node 15: 399 of 1630, fair share 204
+    assert all(k == 1 for _n, _g, k in split_balanced_assignment(cfg3, 4))               # 399 ~ fair share of 4: no split
