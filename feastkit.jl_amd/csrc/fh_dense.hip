@@ -1409,7 +1409,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     // overlap the rest.  Hazards: the rest reads the L columns [K0, Kend) and the pivots of block b and writes only
     // columns >= Kend2; block column b+1 writes only [Kend, Kend2) and its own pivots; its interchanges on the other
     // columns (which touch both) wait for the rest.  Same operations on every element, so the factors are bit-identical.
-    const bool lookahead = h->lu_lookahead != 0 && N > 2 * KB;
+    bool lookahead = h->lu_lookahead != 0 && N > 2 * KB;
     const hipStream_t main_s = h->stream;
     // CUs per XCD left to the main stream: one per panel workgroup the XCD receives (workgroups go round-robin over XCDs)
     const int reserve = getenv("FH_LU_RESERVE") ? atoi(getenv("FH_LU_RESERVE")) : std::min(4, (nf + 7) / 8);
@@ -1436,17 +1436,26 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
             for (int m = 0; m < reserve; ++m) reserved |= (i % 32) == ((i / 32) % 8 + 8 * m);
             if (!reserved) mask[i / 32] |= 1u << (i % 32);
         }
-        if (reserve > 0) FH_CHECK(hipExtStreamCreateWithCUMask(&h->side_stream, (uint32_t)mask.size(), mask.data()));
-        else {
+        // a runtime without CU masks (or a partition mode that refuses them) falls back to the plain low-priority stream,
+        // and without any second stream to the serial order: the look-ahead is an optimisation, never a reason to fail
+        bool have = reserve > 0 && hipExtStreamCreateWithCUMask(&h->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+        if (!have) {
+            (void)hipGetLastError();
+            h->side_stream = nullptr;
             int prio_lo = 0, prio_hi = 0;
-            FH_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-            FH_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo));
+            have = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess &&
+                   hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
+        }
+        if (have && !h->lu_ev_next)
+            have = hipEventCreateWithFlags(&h->lu_ev_next, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->lu_ev_rest, hipEventDisableTiming) == hipSuccess;
+        if (!have) {
+            (void)hipGetLastError();
+            if (h->side_stream) { (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
+            h->lu_lookahead = 0;
+            lookahead = false;
         }
         h->side_reserve = reserve;
-        if (!h->lu_ev_next) {
-            FH_CHECK(hipEventCreateWithFlags(&h->lu_ev_next, hipEventDisableTiming));
-            FH_CHECK(hipEventCreateWithFlags(&h->lu_ev_rest, hipEventDisableTiming));
-        }
     }
     // measured (cfg 2 sweeps): no look-ahead 84 ms, plain side stream 79, plain + 4 chunks 74, CU mask 68, mask + chunks 72
     const int lu_chunks = getenv("FH_LU_CHUNKS") ? std::max(1, atoi(getenv("FH_LU_CHUNKS"))) : (reserve > 0 ? 1 : KB / LU_NB);
