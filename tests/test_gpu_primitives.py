@@ -140,6 +140,40 @@ def test_orthonormalize_reference_kat(engine):
     assert np.linalg.norm(src - Q @ (Q.conj().T @ src)) <= k["span_tol"]
 
 
+@pytest.mark.parametrize("kind", ["well", "graded", "ill"])
+def test_orthonormalize_one_and_two_cholesky_qr_passes(kind, monkeypatch):
+    """Cholesky-QR runs its second pass only when the pivot ratio of the equilibrated Gram matrix is below 1e-2.  "well":
+    Gaussian columns (ratio ~ 1, one pass); "graded": the same columns scaled over four decades (equilibration makes it the
+    first case: still one pass; ten decades would be rank deficient by the reference's |R_ii| / |R_11| rule); "ill": columns 3e-3 apart from each other in angle (ratio ~ 1e-5: two passes).  In every
+    case the basis is orthonormal to 1e-12, spans the input, and equals -- up to 1e-10 in the projector -- what the
+    always-two-passes form (FH_CHOLQR_TWO_PASS=1) returns."""
+    import feastkit_jl_amd as fk
+    N, m = 3000, 40
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((N, m)) + 1j * rng.standard_normal((N, m))
+    if kind == "graded":
+        X = X * np.logspace(-2, 2, m)[None, :]
+    elif kind == "ill":
+        X = X[:, :1] + 3e-3 * X
+    A, B = sparse_pair(N, 5)
+    out = {}
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("FH_CHOLQR_TWO_PASS", "1")
+        eng = fk.HipEngine(0)
+        eng.set_problem(A, B)
+        dQ = eng.upload(X)
+        rank = eng.orthonormalize(dQ, m, np.sqrt(np.finfo(float).eps))
+        assert rank == m
+        Q = eng.download(dQ)[:, :rank]
+        eng.close()
+        assert np.abs(Q.conj().T @ Q - np.eye(m)).max() < 1e-12
+        assert np.linalg.norm(X - Q @ (Q.conj().T @ X)) <= 1e-9 * np.linalg.norm(X)
+        out[forced] = Q
+    # same subspace: Q1 Q1^H Q2 = Q2
+    assert np.linalg.norm(out[False] @ (out[False].conj().T @ out[True]) - out[True]) < 1e-10
+
+
 def test_moment_kat_on_device(engine):
     """Moment KAT of the reference (test/test_allocation_helpers.jl:219-265) through the device's want_moments path:
     one contour node z = Zne[1], weight Wne[1], B = I and a dense A built so that (z - A)^-1 work = workc, the
