@@ -104,6 +104,36 @@ def test_project_matches_numpy(engine, N, m):
     assert np.abs(At - Q.T @ (A @ Q)).max() <= 1e-11 * np.abs(refA).max()
 
 
+@pytest.mark.parametrize("N,m", [(257, 16), (1000, 33), (2049, 64)])
+def test_real_panels_take_the_one_product_path(engine, N, m):
+    """Panels without imaginary parts (what a real projection of a real pencil produces) make the MFMA Gram and Q V kernels
+    skip three of the four real products, decided from the loaded data.  The results must be those of the complex path:
+    checked against numpy, and against the same call on the panel with ONE entry given a tiny imaginary part (which sends
+    every workgroup that loads it down the four-product path)."""
+    A, B = sparse_pair(N, 21, cplx=False)
+    engine.set_problem(A, B)
+    rng = np.random.default_rng(N + m)
+    Q = rng.standard_normal((N, m)) + 0j
+    dQ = engine.upload(Q)
+    Aq, Bq = engine.project(dQ, m, bilinear=False, hermitize=False)
+    refA, refB = Q.T @ (A @ Q), Q.T @ (B @ Q)
+    assert not Aq.imag.any() and not Bq.imag.any()
+    assert np.abs(Aq - refA).max() <= 1e-12 * np.abs(refA).max()
+    assert np.abs(Bq - refB).max() <= 1e-12 * np.abs(refB).max()
+    Q2 = Q.copy(); Q2[N // 2, m // 2] += 1e-300j
+    A2, B2 = engine.project(engine.upload(Q2), m, bilinear=False, hermitize=False)
+    assert np.array_equal(A2.real, Aq.real) and np.array_equal(B2.real, Bq.real)         # same real parts, bit for bit
+    V = np.asfortranarray(rng.standard_normal((m, m)) + 0j)
+    lam = np.linspace(-1.0, 1.0, m)
+    dX, res = engine.ritz_residual(dQ, m, V, lam, m, normalize=False, use_B=True)
+    X = engine.download(dX)[:, :m]
+    assert not X.imag.any()
+    assert np.abs(X - Q @ V).max() <= 1e-12 * np.abs(Q @ V).max()
+    V2 = V.copy(); V2[0, 0] += 1e-300j
+    dX2, _ = engine.ritz_residual(dQ, m, V2, lam, m, normalize=False, use_B=True)
+    assert np.array_equal(engine.download(dX2)[:, :m].real, X.real)
+
+
 @pytest.mark.parametrize("N,m,true_rank", [(30, 4, 4), (200, 16, 9), (1000, 32, 32), (3000, 64, 40), (500, 10, 3),
                                            (800, 100, 100), (1200, 130, 70), (600, 200, 64)])   # m > 64: block Gram-Schmidt
 def test_orthonormalize_rank_and_span(engine, N, m, true_rank):
