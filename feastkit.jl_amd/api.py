@@ -3,6 +3,8 @@
 package provides.  Everything else of the reference API stays on the Julia host."""
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -48,16 +50,35 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30):
 _KRYLOV_DEFAULT = dict(warm_start=True, inner_rtol=3e-2, solver_maxiter=100)
 
 
+_warned = set()
+
+
+def _warn_substitution(sub):
+    """One warning per process and configuration: the reference's `solver=:direct` means a sparse LU, which this
+    backend replaces by a Krylov solver for patterns that are not a narrow band (also recorded in
+    ``result.stats["solver_substitution"]``)."""
+    key = (sub["used"], sub["warm_start"], sub["inner_rtol"], sub["solver_maxiter"])
+    if key in _warned:
+        return
+    _warned.add(key)
+    warnings.warn("feastkit.jl_amd: solver='direct' on a sparse pattern that is not a narrow band runs the batched "
+                  f"{sub['used']} solver (warm_start={sub['warm_start']}, inner_rtol={sub['inner_rtol']}, "
+                  f"<= {sub['solver_maxiter']} iterations per refinement loop) instead of a sparse LU",
+                  RuntimeWarning, stacklevel=3)
+
+
 def _engine(engine, device):
     return engine if engine is not None else HipEngine(device)
 
 
 def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="direct", solver_tol=0.0,
           solver_maxiter=None, solver_restart=30, warm_start=None, inner_rtol=None, real_projection=None,
-          inner_precision=64, group=None, engine=None, device=0, Q0=None):
+          inner_precision=64, group=None, engine=None, device=0, Q0=None, contour=None):
     """feast(A, [B,] (Emin, Emax); M0, fpm, backend=:hip) for real-symmetric / Hermitian
     dense (numpy) or sparse (scipy) matrices.  Real input is complexified and the result is
     real.(q), exactly as feast_sygv!/feast_scsrgv! do (src/dense/feast_dense.jl:362-387).
+    ``contour=(Zne, Wne)``: caller-supplied half-contour nodes and weights, the reference's "x" drivers
+    (feast_hcsrgvx!/feast_heevx!, test/runtests.jl:415-440).
     """
     if interval is None and B is not None and isinstance(B, tuple):
         B, interval = None, B              # feast(A, (Emin, Emax)) form
@@ -78,23 +99,32 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
     M0 = min(int(M0), N)
     real_input = not (np.iscomplexobj(A.data if sp.issparse(A) else A) or
                       (B is not None and np.iscomplexobj(B.data if sp.issparse(B) else B)))
+    substituted = None
     if sp.issparse(A) and solver in ("direct", "lu"):
         # the reference's sparse default is UMFPACK; the :hip backend has a direct path for band
         # matrices (batched banded LU) and otherwise the batched Krylov solver (north_star)
         solver = _sparse_direct_solver(A, B, int(fpm[2]))
         if solver == "krylov":
             solver = "cocg" if real_input else "bicgstab"
-            if warm_start is None and inner_rtol is None:
-                warm_start, inner_rtol = _KRYLOV_DEFAULT["warm_start"], _KRYLOV_DEFAULT["inner_rtol"]
-                if solver_maxiter is None:
-                    solver_maxiter = _KRYLOV_DEFAULT["solver_maxiter"]
+            # each default applies on its own: naming one of the three keeps the other two
+            if warm_start is None:
+                warm_start = _KRYLOV_DEFAULT["warm_start"]
+            if inner_rtol is None and warm_start:
+                inner_rtol = _KRYLOV_DEFAULT["inner_rtol"]
+            if solver_maxiter is None:
+                solver_maxiter = _KRYLOV_DEFAULT["solver_maxiter"] if (warm_start and inner_rtol is not None) else 500
+            substituted = {"requested": "direct", "used": solver, "warm_start": bool(warm_start),
+                           "inner_rtol": inner_rtol, "solver_maxiter": int(solver_maxiter)}
+            _warn_substitution(substituted)
     warm_start = bool(warm_start)                 # an explicitly named iterative solver keeps the reference's zero guess
     solver_maxiter = 500 if solver_maxiter is None else int(solver_maxiter)
     eng = _engine(engine, device)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,
-                              inner_precision=inner_precision, group=group, Q0=Q0)
+                              inner_precision=inner_precision, group=group, Q0=Q0, contour=contour)
+    if substituted is not None and isinstance(res.stats, dict):
+        res.stats["solver_substitution"] = substituted
     if real_input:
         res = FeastResult(res.lambda_, np.real(res.q), res.M, res.res, res.info, res.epsout, res.loop, res.stats)
     return res
@@ -102,7 +132,7 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
 
 def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend="hip", solver="direct",
                   solver_tol=0.0, solver_maxiter=500, solver_restart=30, group=None, engine=None, device=0, Q0=None,
-                  inner_precision=64):
+                  inner_precision=64, contour=None):
     """feast_general(A, [B,] center, radius; M0, fpm): src/interfaces/feast_interfaces.jl:274-379."""
     if backend not in _BACKENDS:
         raise ValueError(f"Unknown backend '{backend}' (this package provides: hip)")
@@ -113,9 +143,23 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
     fpm = feastinit() if fpm is None else fpm
     feastdefault(fpm)
     M0 = min(int(M0), A.shape[0])
+    substituted = None
     if sp.issparse(A) and solver in ("direct", "lu"):
+        # the reference factors z B - A with UMFPACK (src/sparse/feast_sparse.jl:943); here: banded LU for narrow
+        # bands, else batched BiCGStab on the (non-symmetric) shifted systems with the reference's iterative
+        # settings (zero guess, rtol = atol = 10^-fpm[3], src/sparse/feast_sparse.jl:164-203)
         solver = _sparse_direct_solver(A, B, int(fpm[8]))
+        if solver == "krylov":
+            solver = "bicgstab"
+            substituted = {"requested": "direct", "used": solver, "warm_start": False, "inner_rtol": None,
+                           "solver_maxiter": int(solver_maxiter)}
+            _warn_substitution(substituted)
+    elif solver == "krylov":
+        solver = "bicgstab"
     eng = _engine(engine, device)
-    return feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver, inner_precision=inner_precision,
+    res = feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver, inner_precision=inner_precision,
                              solver_tol=solver_tol, solver_maxiter=solver_maxiter,
-                             solver_restart=solver_restart, group=group, Q0=Q0)
+                             solver_restart=solver_restart, group=group, Q0=Q0, contour=contour)
+    if substituted is not None and isinstance(res.stats, dict):
+        res.stats["solver_substitution"] = substituted
+    return res

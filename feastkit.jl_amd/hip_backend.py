@@ -423,7 +423,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
 
 
 def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
-                      solver_restart=30, group=None, Q0=None, seed=20260515, inner_precision=64):
+                      solver_restart=30, group=None, Q0=None, seed=20260515, inner_precision=64, contour=None):
     """Variant C (general, full contour, no factor 2, no orthonormalisation, residual
     without B): src/kernel/feast_kernel.jl:752-950 driven as in src/dense/feast_dense.jl:468-584."""
     N = A.shape[0]
@@ -440,7 +440,8 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
     Ac = A.astype(np.complex128) if not np.iscomplexobj(A) else A
     Bc = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B) else B)
     engine.set_problem(Ac, Bc)
-    Zne, Wne = feast_gcontour(Emid, r, fpm)
+    # caller-supplied nodes/weights: the reference's "x" drivers (feast_gcsrgvx!/feast_gegvx!, src/sparse/feast_sparse.jl:1008-)
+    Zne, Wne = feast_gcontour(Emid, r, fpm) if contour is None else contour
     engine.set_contour(Zne, Wne, 1.0)
     engine.set_real_projection(False)
     first, count = distribute_contour_points(len(Zne), world)[rank]
