@@ -98,7 +98,9 @@ def feast_contour(Emin, Emax, ne=8, fpm16=0, fpm18=100):
     elif fpm16 == 2:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "feastkit.jl_amd", "zolotarev_tables.json")
+        # the oracle's OWN copy of the reference's constants (src/core/feast_tools.jl:50-180), extracted by
+        # tests/golden/make_zolotarev_tables.py with a parser of its own -- never the file the product ships
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "zolotarev_tables.json")
         tab = json.load(open(path))[str(ne)]
         for e in range(ne):
             xr, xi, wr, wi = tab["nodes"][e]

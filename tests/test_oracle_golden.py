@@ -204,3 +204,22 @@ def test_closed_form_cfg3_small():
     assert r.epsout <= 1e-12 and r.loop > 20
     r20 = fo.feast_hermitian(A, B, 0.0, 2.0, len(inside) + 10, ne=8)
     assert r20.info == fo.FEAST_ERROR_NO_CONVERGENCE and r20.M == len(inside)
+
+
+def test_zolotarev_tables_oracle_copy_equals_product_copy():
+    """The oracle reads tests/golden/zolotarev_tables.json, the product feastkit.jl_amd/zolotarev_tables.json; the two
+    were extracted from src/core/feast_tools.jl:50-180 by different parsers (tests/golden/make_zolotarev_tables.py) and
+    must hold the same numbers.  Spot values are pinned against the reference's literals (n = 1 and n = 2, :52-60)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = json.load(open(os.path.join(root, "tests", "golden", "zolotarev_tables.json")))
+    b = json.load(open(os.path.join(root, "feastkit.jl_amd", "zolotarev_tables.json")))
+    assert a == b
+    assert sorted(int(k) for k in a) == [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20]
+    for n, tab in a.items():
+        assert len(tab["nodes"]) == int(n) and len(tab["we0"]) == 2
+    assert a["1"]["we0"] == [-0.49800399400799011, 0.0] and a["1"]["nodes"][0] == [0.0, 1.0, 0.0, 0.99800399400799011]
+    assert a["2"]["nodes"][1] == [0.99900149850137365, 0.044676682867128663, 0.040933604666346268, 0.0018306055366585177]
+    src = open(os.path.join(root, "oracle", "feast_oracle.py")).read()
+    assert "feastkit.jl_amd" not in src.split("def feast_contour")[1].split("def feast_gcontour")[0]
