@@ -23,10 +23,14 @@ def _is_hermitian(A, tol=0.0):
     return np.array_equal(A, A.conj().T)
 
 
-def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30):
-    """``solver=:direct`` for sparse input: "banded" when the union pattern of A and B is a narrow band
-    whose LU factors (2 kl + ku + 1 rows per column and node, complex128) fit the budget, else the
-    Krylov default."""
+def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30, dense_limit=12288):
+    """``solver=:direct`` for sparse input (UMFPACK in the reference, src/sparse/feast_sparse.jl:334-342, :943):
+      "banded" -- the union pattern of A and B is a narrow band whose LU factors (2 kl + ku + 1 rows per column and
+                  node, complex128) fit the budget: batched banded LU on the CSR arrays;
+      "dense"  -- any other pattern up to N = dense_limit whose N x N complex128 factors (one per node, plus A and B)
+                  fit the budget: the matrix is expanded on ingest and factored by the batched dense LU -- an exact
+                  direct solve like the reference's, at O(N^3) per node, which the MFMA LU affords at these sizes;
+      "krylov" -- everything larger: the batched Krylov solvers (north_star's iterative path)."""
     kl = ku = 0
     for M in (A, B):
         if M is None:
@@ -36,9 +40,16 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30):
             kl = max(kl, int((c.row - c.col).max()))
             ku = max(ku, int((c.col - c.row).max()))
     ldab = 2 * kl + ku + 1
-    if 2 * kl + ku + 1 <= 3500 and ldab * A.shape[0] * 16 * max(nodes, 1) <= budget_bytes and kl + ku <= 512:
+    N = A.shape[0]
+    if 2 * kl + ku + 1 <= 3500 and ldab * N * 16 * max(nodes, 1) <= budget_bytes and kl + ku <= 512:
         return "banded"
+    if N <= dense_limit and (max(nodes, 1) + 2) * N * N * 16 <= budget_bytes:
+        return "dense"
     return "krylov"
+
+
+def _densify(M):
+    return None if M is None else np.asfortranarray(M.toarray())
 
 
 # What `solver=:direct` (the reference's default, UMFPACK for sparse input: src/sparse/feast_sparse.jl:334-342 via
@@ -104,7 +115,10 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         # the reference's sparse default is UMFPACK; the :hip backend has a direct path for band
         # matrices (batched banded LU) and otherwise the batched Krylov solver (north_star)
         solver = _sparse_direct_solver(A, B, int(fpm[2]))
-        if solver == "krylov":
+        if solver == "dense":
+            A, B, solver = _densify(A), _densify(B), "direct"
+            substituted = {"requested": "direct", "used": "dense LU of the expanded matrix"}
+        elif solver == "krylov":
             solver = "cocg" if real_input else "bicgstab"
             # each default applies on its own: naming one of the three keeps the other two
             if warm_start is None:
@@ -149,7 +163,10 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
         # bands, else batched BiCGStab on the (non-symmetric) shifted systems with the reference's iterative
         # settings (zero guess, rtol = atol = 10^-fpm[3], src/sparse/feast_sparse.jl:164-203)
         solver = _sparse_direct_solver(A, B, int(fpm[8]))
-        if solver == "krylov":
+        if solver == "dense":
+            A, B, solver = _densify(A), _densify(B), "direct"
+            substituted = {"requested": "direct", "used": "dense LU of the expanded matrix"}
+        elif solver == "krylov":
             solver = "bicgstab"
             substituted = {"requested": "direct", "used": solver, "warm_start": False, "inner_rtol": None,
                            "solver_maxiter": int(solver_maxiter)}

@@ -40,6 +40,24 @@ int fh_get_buf(feasthip_ctx* h, const char* name, size_t bytes, void** out) {
     return 0;
 }
 
+// A call is about to return an error while its kernels may still be queued or running on h->stream (progress
+// deadline, faulted queue).  Give the stream a bounded chance to drain; if it does not, the handle is POISONED: the
+// workspaces those kernels use must not be reused or freed, so every later call fails fast until destroy (which then
+// skips the stream synchronisation and leaks the buffers to the process -- the host must exit non-zero or continue in
+// a fresh process; see include/feasthip.h).
+static void fh_poison_unless_drained(feasthip_ctx* h, double grace_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) return;                        // drained: the handle stays usable
+        if (q != hipErrorNotReady) break;                   // the queue itself reports a fault
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > grace_s) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+    h->poisoned = 1;
+    h->last_error += " [handle poisoned: device work may still be in flight; destroy the handle and exit the process]";
+}
+
 void fh_free_bufs(feasthip_ctx* h) {
     for (auto& kv : h->bufs) hipFree(kv.second.first);
     h->bufs.clear();
@@ -183,6 +201,13 @@ static void fh_free_problem(feasthip_ctx* h) {
 extern "C" int feasthip_destroy(feasthip_handle h) {
     if (!h) return 0;
     hipSetDevice(h->device);
+    if (h->poisoned) {
+        // kernels of a failed call may still be running on the workspaces: neither wait for them (a wedged kernel
+        // never ends) nor free what they touch.  The memory goes back to the driver when the process exits.
+        fh_comm_mark_failed(h);
+        delete h;
+        return 0;
+    }
     hipStreamSynchronize(h->stream);
     fh_comm_destroy(h);
     fh_prof_collect(h);
@@ -204,6 +229,7 @@ extern "C" const char* feasthip_last_error(feasthip_handle h) { return h ? h->la
 
 extern "C" int feasthip_set_stream(feasthip_handle h, void* hip_stream) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
     hipStreamSynchronize(h->stream);
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return 0;
@@ -211,6 +237,7 @@ extern "C" int feasthip_set_stream(feasthip_handle h, void* hip_stream) {
 
 extern "C" int feasthip_synchronize(feasthip_handle h) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
     FH_CHECK(hipSetDevice(h->device));
     FH_CHECK(hipStreamSynchronize(h->stream));
     fh_prof_collect(h);
@@ -609,7 +636,9 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
         a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m; a.uniform_coef = c.uniform_coef; a.prec = c.prec;
         static const bool no_lds = getenv("FH_NO_LDS_SPMM") != nullptr;
-        const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds;
+        // (the LDS-window kernel keeps its active-node list in a 64-entry LDS array: wider node batches -- trapezoid
+        //  contours put no bound on fpm[2] -- take the gather kernel, which has no such limit)
+        const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds && c.nodes <= 64;
         a.nblk_rows = h->csr.nblk; a.blk_start = h->csr.blk_start; a.ext_ptr = h->csr.ext_ptr; a.ext_idx = h->csr.ext_idx;
         a.lcol = lds_kernel ? h->csr.lcol : nullptr;
         fh_prof_begin(h, "spmm");
@@ -646,6 +675,7 @@ static bool fh_b_identity(feasthip_ctx* h) { return h->kind == 2 ? h->csr.b_iden
 // wide = 1: the entry point also takes m > FH_MAX_LD (processed in 64-column panels)
 static int fh_check_problem(feasthip_ctx* h, int64_t m, int wide = 0) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
     if (h->kind == 0) { h->last_error = "no matrix set (feasthip_set_dense / feasthip_set_csr)"; return FEASTHIP_ERROR_N; }
     if (m <= 0 || (!wide && m > FH_MAX_LD) || m > fh_N(h)) {
         h->last_error = wide ? "block width m must satisfy 1 <= m <= N" : "block width m must satisfy 1 <= m <= min(N, 64)";
@@ -891,6 +921,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                 const hipError_t q = hipStreamQuery(h->stream);
                 if (q != hipSuccess && q != hipErrorNotReady) {
                     h->last_error = std::string("device queue failed while iterating: ") + hipGetErrorString(q);
+                    h->poisoned = 1;
                     return FEASTHIP_ERROR_INTERNAL;
                 }
                 // a wedged kernel keeps answering "not ready": overall deadline, generous against the slowest
@@ -899,6 +930,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                 const double budget = 30.0 + 0.05 * (double)h->maxit * (1.0 + (double)N * nodes / 8.0e5);
                 if (waited > budget) {
                     h->last_error = "device did not make progress on the Krylov iterations within the deadline (" + std::to_string((int)budget) + " s)";
+                    fh_poison_unless_drained(h, 2.0);
                     return FEASTHIP_ERROR_INTERNAL;
                 }
             }
@@ -957,9 +989,27 @@ static int fh_gmres(feasthip_ctx* h, int ld, int m, int nodes_all, const std::ve
     res.status.assign(nodes_all, 0);
     // node batches: the basis costs (mr + 2) panels per node
     const size_t per_node = (size_t)(mr + 2) * panel * sizeof(cplx);
+    // budget: at most 48 GiB and at most half of what the device has free right now (plus what this handle already
+    // holds for the basis) -- several ranks may share one card (shm rehearsal layout), and parts with less HBM exist
     size_t budget = (size_t)48 << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            auto held = h->bufs.find("gm_V");
+            const size_t avail = free_b / 2 + (held != h->bufs.end() ? held->second.second : 0);
+            budget = std::min(budget, std::max(avail, per_node));
+        }
+    }
     if (getenv("FH_GMRES_BUDGET_MB")) budget = (size_t)std::max(1, atoi(getenv("FH_GMRES_BUDGET_MB"))) << 20;
-    const int nbatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)nodes_all, budget / std::max<size_t>(per_node, 1)));
+    int nbatch = (int)std::max<size_t>(1, std::min<size_t>((size_t)nodes_all, budget / std::max<size_t>(per_node, 1)));
+    // an allocation failure halves the batch before it becomes an error
+    for (;;) {
+        if (fh_get_buf(h, "gm_V", (size_t)nbatch * (mr + 1) * panel * sizeof(cplx), &p) == 0 &&
+            fh_get_buf(h, "gm_W", (size_t)nbatch * panel * sizeof(cplx), &p) == 0) break;
+        if (nbatch == 1) return FEASTHIP_ERROR_MEMORY;
+        hipGetLastError();                                   // clear the sticky out-of-memory status
+        nbatch = (nbatch + 1) / 2;
+    }
     const int nblk_vec = fh_kry_nblk(N, ld, nbatch);
     const int nblk_op = fh_op_nblk(h, ld);
     for (int e0 = 0; e0 < nodes_all; e0 += nbatch) {
@@ -1227,7 +1277,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         if (h->kind == 2 && h->csr.perm) {
-            h->last_error = "banded LU needs the matrix in the caller's order; this pattern is too wide for it (renumbered into row blocks at ingest)";
+            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER; mode 2 renumbers narrow bands too): unset FH_REORDER or pick a Krylov solver";
             return FEASTHIP_ERROR_FPM;
         }
         int64_t nfact = 0;
@@ -1469,63 +1519,95 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     if (h->col_block_hi >= 0) { c0 = std::min(h->col_block_lo, m64); c1 = std::min(std::max(h->col_block_hi, c0), m64); }
     const bool full = (c0 == 0 && c1 == m64);
     if (nr == 1 && full) return fh_contour_apply_local(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
+    // The shape of the packed reduce depends only on what every rank was called with (N, m, ne, the moment pointers, the
+    // projection mode).  An argument error is therefore the same on every rank and may return at once; anything that
+    // can fail on ONE rank only (allocations, the sweep, copies) is recorded in local_rc and the rank still joins the
+    // reduce with a zeroed payload and its failure flag set -- its peers are waiting in the collective, and RCCL has no
+    // timeout.
     int rc = fh_check_problem(h, m64, 1);
     if (rc) return rc;
     if (!full && (dzAq || dzSq)) { h->last_error = "contour_apply: moment matrices need the full column block"; return FEASTHIP_ERROR_M0; }
-    FH_CHECK(hipSetDevice(h->device));
     const int N = (int)fh_N(h), m = (int)m64, nodes = h->node_count, ne = (int)h->zne.size();
     std::vector<int> ns(std::max(nodes, 1), 0);
     if (stats) memset(stats, 0, sizeof(*stats));
-    if (!full) FH_CHECK(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream));
-    if (c1 > c0) {
+    int local_rc = 0;
+    auto soft = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && !local_rc) {
+            h->last_error = std::string(what) + ": " + hipGetErrorString(e);
+            local_rc = (e == hipErrorOutOfMemory) ? FEASTHIP_ERROR_MEMORY : FEASTHIP_ERROR_INTERNAL;
+        }
+    };
+    soft(hipSetDevice(h->device), "hipSetDevice");
+    // the reduce buffer comes first: without it this rank cannot join the collective at all
+    const size_t nq = (size_t)N * m * (h->real_projection ? 1 : 2);
+    const size_t nm = (size_t)m * m * 2;
+    const size_t total = nq + (dzAq ? nm : 0) + (dzSq ? nm : 0) + 3 * (size_t)ne + 1;
+    double* pack = nullptr;
+    if (nr > 1) {
+        void* p = nullptr;
+        if ((rc = fh_get_buf(h, "comm_pack", total * sizeof(double), &p))) {
+            // nothing to reduce into: tell the peers through the transport's own failure path where there is one
+            // (shm: the failed flag releases their barriers), then give up -- the caller must treat this as fatal
+            fh_comm_mark_failed(h);
+            return rc;
+        }
+        pack = (double*)p;
+    }
+    if (!local_rc && !full) soft(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream), "hipMemsetAsync(Q_proj)");
+    if (!local_rc && c1 > c0) {
         const std::vector<int> mask = h->col_mask;
         if (!mask.empty()) {
             h->col_mask.clear();
             for (int64_t c = c0; c < c1; ++c) h->col_mask.push_back(c < (int64_t)mask.size() ? mask[c] : 1);
         }
-        rc = fh_contour_apply_local(h, c1 - c0, dQ + (size_t)c0 * N, ritz_lambda ? ritz_lambda + c0 : nullptr,
-                                    dQproj + (size_t)c0 * N, dzAq, dzSq, ns.data(), stats);
+        local_rc = fh_contour_apply_local(h, c1 - c0, dQ + (size_t)c0 * N, ritz_lambda ? ritz_lambda + c0 : nullptr,
+                                          dQproj + (size_t)c0 * N, dzAq, dzSq, ns.data(), stats);
         h->col_mask = mask;
-    } else {
-        FH_CHECK(hipStreamSynchronize(h->stream));
+    } else if (!local_rc) {
+        soft(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
     }
     if (nr == 1) {
-        if (rc) return rc;
+        if (local_rc) return local_rc;
         if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = ns[e];
         return 0;
     }
-    // a rank whose sweep failed still takes part in the reduce (its peers are waiting in it) and reports through
-    // the flags: every rank then sees the failure instead of blocking
-    const int local_rc = rc;
-    const size_t nq = (size_t)N * m * (h->real_projection ? 1 : 2);
-    const size_t nm = (size_t)m * m * 2;
-    const size_t total = nq + (dzAq ? nm : 0) + (dzSq ? nm : 0) + 3 * (size_t)ne + 1;
-    void* p;
-    if ((rc = fh_get_buf(h, "comm_pack", total * sizeof(double), &p))) return rc;
-    double* pack = (double*)p;
-    if (h->real_projection) fh_launch_pack_real(dQproj, pack, nq, h->stream);
-    else FH_CHECK(hipMemcpyAsync(pack, dQproj, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     size_t off = nq;
-    if (dzAq) { FH_CHECK(hipMemcpyAsync(pack + off, dzAq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
-    if (dzSq) { FH_CHECK(hipMemcpyAsync(pack + off, dzSq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
+    if (!local_rc) {
+        if (h->real_projection) fh_launch_pack_real(dQproj, pack, nq, h->stream);
+        else soft(hipMemcpyAsync(pack, dQproj, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "pack Q_proj");
+        if (dzAq) { soft(hipMemcpyAsync(pack + off, dzAq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "pack zAq"); off += nm; }
+        if (dzSq) { soft(hipMemcpyAsync(pack + off, dzSq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "pack zSq"); off += nm; }
+    } else {
+        off += (dzAq ? nm : 0) + (dzSq ? nm : 0);
+    }
     // tail of the packed buffer: [no-convergence flags | singular flags | Krylov iterations per contour node | rank failed]
     std::vector<double> flags(3 * (size_t)ne + 1, 0.0);
-    for (int e = 0; e < nodes; ++e) {
+    for (int e = 0; e < nodes && !local_rc; ++e) {
         const int g = h->node_ids[e];
         if (ns[e] == FEASTHIP_ERROR_LAPACK) flags[ne + g] = 1.0;
         else if (ns[e] != 0) flags[g] = 1.0;
         if (c1 > c0 && e < (int)h->last_node_iters.size()) flags[2 * (size_t)ne + g] = (double)h->last_node_iters[e];
     }
-    flags[3 * (size_t)ne] = local_rc ? 1.0 : 0.0;
-    FH_CHECK(hipMemcpyAsync(pack + off, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipError_t e_flags = hipSuccess;
     if (local_rc) {
         // our own payload may be garbage: contribute zeros so that the peers' sums stay finite
-        FH_CHECK(hipMemsetAsync(pack, 0, off * sizeof(double), h->stream));
+        e_flags = hipMemsetAsync(pack, 0, off * sizeof(double), h->stream);
+    }
+    flags[3 * (size_t)ne] = local_rc ? 1.0 : 0.0;
+    if (e_flags == hipSuccess) e_flags = hipMemcpyAsync(pack + off, flags.data(), flags.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e_flags != hipSuccess) {
+        // the stream itself refuses work: the flag cannot be shipped.  Still enter the collective (whatever the buffer
+        // holds) so that the peers return; this rank reports the error
+        soft(e_flags, "pack flags");
     }
     fh_prof_begin(h, "allreduce");
     rc = fh_comm_allreduce_sum(h, pack, total);
     fh_prof_end(h);
-    if (rc) return rc;
+    if (rc) return local_rc ? local_rc : rc;
+    if (local_rc) {
+        hipStreamSynchronize(h->stream);          // best effort: leave no work of ours queued behind the error
+        return local_rc;
+    }
     if (h->real_projection) fh_launch_unpack_real(pack, dQproj, nq, h->stream);
     else FH_CHECK(hipMemcpyAsync(dQproj, pack, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     off = nq;
@@ -1538,7 +1620,6 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
             node_status[g] = flags[ne + g] > 0.0 ? (int)FEASTHIP_ERROR_LAPACK : (flags[g] > 0.0 ? (int)FEASTHIP_ERROR_NO_CONVERGENCE : 0);
     h->global_node_iters.assign(ne, 0);
     for (int g = 0; g < ne; ++g) h->global_node_iters[g] = (int)(flags[2 * (size_t)ne + g] + 0.5);
-    if (local_rc) return local_rc;
     if (flags[3 * (size_t)ne] > 0.0) { h->last_error = "contour_apply: the sweep failed on another rank"; return FEASTHIP_ERROR_INTERNAL; }
     return 0;
 }
@@ -2465,7 +2546,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         if (h->kind == 2 && h->csr.perm) {
-            h->last_error = "banded LU needs the matrix in the caller's order; this pattern is too wide for it (renumbered into row blocks at ingest)";
+            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER; mode 2 renumbers narrow bands too): unset FH_REORDER or pick a Krylov solver";
             return FEASTHIP_ERROR_FPM;
         }
         int64_t nfact = 0;

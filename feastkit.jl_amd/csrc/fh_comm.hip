@@ -16,6 +16,8 @@
 #include "fh_comm.hpp"
 #include "../../include/feasthip.h"
 
+#include <rccl/rccl.h>       // types only: the library itself is resolved with dlopen at run time
+
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -34,6 +36,7 @@ struct rccl_api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
@@ -60,6 +63,7 @@ rccl_api* rccl() {
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");       // optional
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) {
@@ -279,11 +283,22 @@ extern "C" int feasthip_comm_info(feasthip_handle h, int* nranks, int* rank, int
 int fh_comm_nranks(feasthip_ctx* h) { return h->comm ? h->comm->nranks : 1; }
 int fh_comm_rank(feasthip_ctx* h) { return h->comm ? h->comm->rank : 0; }
 
+void fh_comm_mark_failed(feasthip_ctx* h) {
+    fh_comm* c = h->comm;
+    if (!c || c->nranks == 1) return;
+    if (c->transport == FEASTHIP_COMM_RCCL) {
+        if (c->nccl && rccl()->CommAbort) { rccl()->CommAbort(c->nccl); c->nccl = nullptr; }
+    } else if (c->seg) {
+        c->seg->failed.store(1);
+    }
+}
+
 // In-place sum over the ranks of `count` doubles at device pointer d, ordered on the handle's stream.
 int fh_comm_allreduce_sum(feasthip_ctx* h, double* d, size_t count) {
     fh_comm* c = h->comm;
     if (!c || c->nranks == 1 || count == 0) return 0;
     if (c->transport == FEASTHIP_COMM_RCCL) {
+        if (!c->nccl) { h->last_error = "comm(rccl): the communicator was aborted after an earlier failure"; return FEASTHIP_ERROR_INTERNAL; }
         ncclResult_t e = rccl()->AllReduce(d, d, count, ncclDouble, ncclSum, c->nccl, h->stream);
         if (e != ncclSuccess) {
             h->last_error = std::string("ncclAllReduce: ") + (rccl()->GetErrorString ? rccl()->GetErrorString(e) : "error");

@@ -172,6 +172,7 @@ struct feasthip_ctx {
     std::vector<int> band_valid;
     std::vector<cplx> band_z;
     std::vector<int> col_mask;    // feasthip_set_column_mask: columns with 0 are not iterated by the Krylov solvers
+    int poisoned = 0;             // a Krylov deadline / queue fault returned with kernels possibly still queued: every later call fails fast
     int mask_live = 0;            // set only while a contour_apply call runs: the mask is one-shot and never reaches shifted_solve
     int sum_mode = 1;             // COCG contour_apply accumulates alpha*p into one shared panel (FH_NO_SUM_MODE=1 disables)
     int lu_outer_block = 0;       // FH_LU_KB: outer block column of the two-level LU (multiple of 32); 0 = by size (128, 256 from N = 6144)

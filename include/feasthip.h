@@ -167,12 +167,18 @@ int  feasthip_set_column_block(feasthip_handle h, int64_t first, int64_t count);
 
 /* Inexact-FEAST extension (not in the reference): columns c < m with mask[c] == 0 keep their initial
  * guess (the Ritz warm start q_c/(z - lambda_c) when ritz_lambda is given) and are never iterated by
- * the Krylov solvers of the following contour_apply calls.  Used to stop spending solves on the
+ * the BiCGStab / COCG solvers of the following contour_apply calls (the restarted GMRES path ignores the
+ * mask: all columns of a node advance in lock-step through one Arnoldi basis).  Used to stop spending solves on the
  * guard columns (Ritz values outside the interval) once the subspace has settled.  mask == NULL or
  * m == 0 clears it.  Ignored by the LU path.  The mask is ONE-SHOT: it is consumed by the next
  * contour_apply call (cleared when that call returns, whatever its outcome) and never applies to
  * feasthip_shifted_solve.                                                                    */
 int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
+
+/* Error 7 with "handle poisoned" in feasthip_last_error: a Krylov sweep missed its progress deadline or the device
+ * queue faulted, and kernels of the failed call may still be in flight.  Every later call on the handle fails fast;
+ * feasthip_destroy then neither waits for the stream nor frees the workspaces.  The host must end the process with a
+ * non-zero status (or continue in a fresh child process) -- never re-exec a process that has touched the GPU.  */
 
 /* Solver options: keyword args solver/solver_tol/solver_maxiter/solver_restart
  * (src/dense/feast_dense.jl:81-84).  Iterative stop test is Krylov.jl's

@@ -41,41 +41,76 @@ def test_general2_sparse_default_call(engine):
     assert np.allclose(np.sort(r.lambda_.real), k["expect_generalized"], atol=k["atol"])
 
 
-def test_sparse_general_default_call_wide_pattern(engine):
-    """The call that raised ValueError in round 2: feast_general(A_csr) with default keywords on a pattern that
-    is not a narrow band.  `solver=:direct` maps to batched BiCGStab (recorded in stats, warned once)."""
-    N = 2400                      # kl + ku > 512: outside the banded-LU window of _sparse_direct_solver
-    rng = np.random.default_rng(11)
-    delta = 4.0 * np.sqrt(rng.random(N)) * np.exp(2j * np.pi * rng.random(N))
-    delta[:6] = [0.3 + 0.1j, -0.2 + 0.4j, 0.5 - 0.3j, -0.4 - 0.2j, 0.1 + 0.6j, 0.0 - 0.5j]
-    delta[6:] = np.where(np.abs(delta[6:]) < 1.2, delta[6:] * 1.2 / np.maximum(np.abs(delta[6:]), 1e-3), delta[6:])
+def _corner_coupled_diag(delta):
+    """diag(delta) + a sparse superdiagonal + two far-corner entries: non-normal, and NOT a narrow band."""
+    N = len(delta)
     A = sp.lil_matrix(sp.diags(delta), dtype=np.complex128)
     for i in range(0, N - 1, 7):
         A[i, i + 1] = 0.02
     A[0, N - 1] = 0.01 + 0.02j
     A[N - 1, 3] = -0.015j
-    A = sp.csr_matrix(A)
-    inside = delta[np.abs(delta) <= 0.8]
-    assert len(inside) == 6
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        fk.api._warned.clear()
-        # M0 = the number of eigenvalues inside: variant C carries all M0 columns un-orthonormalised, and columns
-        # beyond the invariant subspace are filtered to rounding noise within a few loops (the reduced B matrix turns
-        # singular and spurious Ritz values appear -- the oracle shows the same with M0 = 7: the reference's own
-        # general tests all use M0 = n for that reason)
-        r = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine)
-    assert any("instead of a sparse LU" in str(x.message) for x in w)
-    assert r.stats["solver_substitution"]["used"] == "bicgstab"
+    return sp.csr_matrix(A)
+
+
+def test_sparse_general_default_call_wide_pattern(engine):
+    """The call that raised ValueError in round 2: feast_general(A_csr) with default keywords on a pattern that is not
+    a narrow band.  At this size `solver=:direct` (UMFPACK in the reference) is served by the batched dense LU on the
+    expanded matrix -- an exact direct solve.  The spectrum SURROUNDS the contour here (a disc of radius 4 around a
+    contour of radius 0.8), the situation of BASELINE cfg 5, where no unpreconditioned Krylov method converges (a
+    polynomial with p(0) = 1 cannot be small on a disc around 0): the reference's own GMRES option returns info = 5."""
+    N = 2400
+    rng = np.random.default_rng(11)
+    delta = 4.0 * np.sqrt(rng.random(N)) * np.exp(2j * np.pi * rng.random(N))
+    delta[:6] = [0.3 + 0.1j, -0.2 + 0.4j, 0.5 - 0.3j, -0.4 - 0.2j, 0.1 + 0.6j, 0.0 - 0.5j]
+    delta[6:] = np.where(np.abs(delta[6:]) < 1.2, delta[6:] * 1.2 / np.maximum(np.abs(delta[6:]), 1e-3), delta[6:])
+    A = _corner_coupled_diag(delta)
+    assert fk.api._sparse_direct_solver(A, None, 16) == "dense"
+    # M0 = the number of eigenvalues inside: variant C carries all M0 columns un-orthonormalised, and columns beyond the
+    # invariant subspace are filtered to rounding noise within a few loops (the reduced B matrix turns singular and
+    # spurious Ritz values appear -- the oracle shows the same with M0 = 7; the reference's own general tests all use
+    # M0 = n for that reason)
+    r = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine)
+    assert r.stats["solver_substitution"]["used"].startswith("dense LU")
     assert r.info == 0 and r.M == 6
     ev = np.linalg.eigvals(A.toarray())
     want = ev[np.abs(ev) <= 0.8]
     assert np.allclose(sorted(r.lambda_, key=ckey), sorted(want, key=ckey), atol=1e-9)
     o = fo.feast_general(A, None, 0.0, 0.8, 6, ne=16)
     assert o.info == 0 and o.M == 6 and np.allclose(sorted(o.lam, key=ckey), sorted(r.lambda_, key=ckey), atol=1e-9)
-    Ad = A.toarray()
-    res = np.linalg.norm(Ad @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0)
+    assert r.loop == o.loop
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0)
     assert res.max() <= 1e-9
+    # the same matrix through the iterative keyword: the reference semantics are "return info = 5", not an exception
+    ri = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine, solver="gmres", solver_maxiter=60)
+    assert ri.info == 5 and ri.M == 0
+
+
+def test_sparse_general_default_call_large_maps_to_krylov(engine):
+    """Beyond the dense window the default maps to batched BiCGStab with the reference's iterative settings (zero guess,
+    rtol = atol = 10^-fpm[3], 500 iterations), recorded in stats and warned once.  N = 14 000 with the bulk of the
+    spectrum in a disc AWAY from the contour (centre 10, radius 2) and six eigenvalues inside it: z - A then has a
+    clustered spectrum off the origin plus six outliers and BiCGStab converges in a few dozen iterations."""
+    N = 14000
+    rng = np.random.default_rng(12)
+    delta = 10.0 + 2.0 * np.sqrt(rng.random(N)) * np.exp(2j * np.pi * rng.random(N))
+    delta[:6] = [0.3 + 0.1j, -0.2 + 0.4j, 0.5 - 0.3j, -0.4 - 0.2j, 0.1 + 0.6j, 0.0 - 0.5j]
+    A = _corner_coupled_diag(delta)
+    assert fk.api._sparse_direct_solver(A, None, 16) == "krylov"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        fk.api._warned.clear()
+        r = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine)
+    assert any("instead of a sparse LU" in str(x.message) for x in w)
+    assert r.stats["solver_substitution"]["used"] == "bicgstab"
+    assert r.info == 0 and r.M == 6 and r.stats["krylov_iterations"] > 0
+    o = fo.feast_general(A, None, 0.0, 0.8, 6, ne=16)                     # sparse LU per node
+    assert o.info == 0 and o.M == 6
+    assert np.allclose(sorted(r.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-9)
+    assert abs(r.loop - o.loop) <= 1 and r.epsout <= 1e-11
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0)
+    assert res.max() <= 1e-10
+    rg = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine, solver="gmres")
+    assert rg.info == 0 and np.allclose(sorted(rg.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-9)
 
 
 @pytest.mark.parametrize("generalized", [True, False])
@@ -117,8 +152,8 @@ def test_mpi_complex_general_fixture_on_csr(engine):
 
 def test_cfg5_shaped_sparse_non_normal_vs_oracle(engine):
     """cfg 5 in sparse clothing, reduced: T = diag(delta) + 0.05 U with U sparse strictly upper (non-normal), a
-    sparse similarity by 2x2 rotations so the matrix is not triangular; eigenvalues = delta exactly.  BiCGStab and
-    GMRES on the general shifted systems against fo.feast_general (sparse LU), loop for loop."""
+    sparse similarity by 2x2 rotations so the matrix is not triangular; eigenvalues = delta exactly.  The default call
+    against fo.feast_general (sparse LU per node), loop for loop."""
     N = 1500
     rng = np.random.default_rng(20260515)
     delta = 6.0 * np.sqrt(rng.random(N)) * np.exp(2j * np.pi * rng.random(N))
@@ -142,16 +177,18 @@ def test_cfg5_shaped_sparse_non_normal_vs_oracle(engine):
     assert len(inside) == 30
     o = fo.feast_general(A, None, 0.0, rad, M0, ne=24, fpm4=40)
     assert o.info == 0 and o.M == len(inside)
-    for solver in ("bicgstab", "gmres"):
-        r = fk.feast_general(A, None, 0.0, rad, M0=M0, fpm=fpm_with(f8=24, f4=40), engine=engine, solver=solver,
-                             solver_maxiter=3000, solver_restart=40)
-        assert r.info == 0 and r.M == len(inside), (solver, r.info, r.M)
-        assert np.allclose(sorted(r.lambda_, key=ckey), sorted(inside, key=ckey), atol=1e-9), solver
-        assert np.allclose(sorted(r.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-9), solver
-        assert abs(r.loop - o.loop) <= 1, (solver, r.loop, o.loop)
+    # default call: solver=:direct.  The spectrum surrounds the contour (cfg 5's situation), so this is a job for a
+    # direct solver; the sparse pattern is expanded and factored by the batched dense LU, in complex128 and (BASELINE
+    # cfg 5 as written) with complex64 factors + fp64 refinement
+    for prec in (64, 32):
+        r = fk.feast_general(A, None, 0.0, rad, M0=M0, fpm=fpm_with(f8=24, f4=40), engine=engine, inner_precision=prec)
+        assert r.info == 0 and r.M == len(inside), (prec, r.info, r.M)
+        assert np.allclose(sorted(r.lambda_, key=ckey), sorted(inside, key=ckey), atol=1e-9), prec
+        assert np.allclose(sorted(r.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-9), prec
+        assert abs(r.loop - o.loop) <= 1, (prec, r.loop, o.loop)
         assert r.epsout <= 1e-11
         res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0) / np.maximum(np.abs(r.lambda_), 1)
-        assert res.max() <= 1e-10, solver
+        assert res.max() <= 1e-10, prec
 
 
 def test_custom_contour_hermitian_x_driver(engine):
