@@ -386,7 +386,7 @@ def _splu(S):
 
 def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18=100,
                     solver="direct", solver_tol=0.0, solver_maxiter=500, solver_restart=30,
-                    Q0=None, seed=20260515, contour=None, collect=None, real_projection=False):
+                    Q0=None, seed=20260515, contour=None, collect=None, real_projection=False, sweep=None):
     """Variant A.  A (and B or None) dense ndarray or scipy sparse, Hermitian.
 
     real_projection=False is the reference as written (complex half-contour sum).  True
@@ -398,6 +398,10 @@ def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18
 
     ``collect``: optional dict; when given, per-loop intermediates (Q_proj,
     rank, lambda, epsout) are appended for golden-vector generation.
+
+    ``sweep``: optional callable(Q[:, :active]) -> sum_e 2 w_e (z_e B - A)^{-1} B Q that replaces the serial node
+    loop below -- oracle/node_farm.py runs the nodes on host processes, the shape of the reference's :threads /
+    :distributed backends (src/parallel/feast_parallel.jl:586-630, 484-503); same arithmetic per node.
     """
     N = A.shape[0]
     if N <= 0:
@@ -437,7 +441,13 @@ def feast_hermitian(A, B, Emin, Emax, M0, ne=8, fpm3=12, fpm4=20, fpm16=0, fpm18
         loop_count = loop_idx
         Q_proj = np.zeros((N, M0), dtype=np.complex128, order="F")
         failed = False
-        for e, z in enumerate(Zne):
+        if sweep is not None:
+            try:
+                Q_proj[:, :active] = sweep(Q_basis[:, :active])
+            except Exception:
+                info = FEAST_ERROR_LAPACK
+                failed = True
+        for e, z in enumerate(Zne if sweep is None else ()):
             weight = 2 * Wne[e]
             basis = Q_basis[:, :active]
             rhs = basis.copy() if Bc is None else Bc @ basis

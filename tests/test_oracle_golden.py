@@ -223,3 +223,23 @@ def test_zolotarev_tables_oracle_copy_equals_product_copy():
     assert a["2"]["nodes"][1] == [0.99900149850137365, 0.044676682867128663, 0.040933604666346268, 0.0018306055366585177]
     src = open(os.path.join(root, "oracle", "feast_oracle.py")).read()
     assert "feastkit.jl_amd" not in src.split("def feast_contour")[1].split("def feast_gcontour")[0]
+
+
+def test_node_farm_sweep_equals_serial_node_loop():
+    """oracle/node_farm.py (the all-cores CPU baseline of bench.py: nodes on host processes, the reference's :threads /
+    :distributed shape, src/parallel/feast_parallel.jl:586-630) returns what the serial node loop returns."""
+    import os
+    from node_farm import NodeFarm
+    A, B, lam = fo.cfg3_problem(10, 8, 6)
+    inside = lam[(lam >= 0.0) & (lam <= 0.8)]
+    before = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    serial = fo.feast_hermitian(A, B, 0.0, 0.8, 24, ne=8, real_projection=True)
+    Z, W = fo.feast_contour(0.0, 0.8, 8)
+    with NodeFarm(A, B, Z, W, 24, workers=3) as farm:
+        par = fo.feast_hermitian(A, B, 0.0, 0.8, 24, ne=8, real_projection=True, sweep=farm.sweep)
+        assert farm.factorizations == 8                         # cached across the refinement loops
+    assert serial.info == par.info == 0 and serial.M == par.M == len(inside) and serial.loop == par.loop
+    assert np.abs(np.sort(serial.lam) - np.sort(par.lam)).max() < 1e-13
+    assert np.abs(np.sort(par.lam) - inside).max() < 1e-12
+    after = set(os.listdir("/dev/shm")) if os.path.isdir("/dev/shm") else set()
+    assert after <= before                                      # no shared-memory segments left behind
