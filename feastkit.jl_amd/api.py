@@ -11,7 +11,7 @@ import scipy.sparse as sp
 from .engine import HipEngine
 from .hip_backend import feast_hip_general, feast_hip_hermitian
 from .parameters import feastdefault, feastinit
-from .types import FeastResult
+from .types import FEAST_UNINITIALIZED, FeastResult
 
 _BACKENDS = ("hip", "auto")   # _normalize_backend whitelist edit, feast_interfaces.jl:44
 
@@ -84,7 +84,7 @@ def _engine(engine, device):
 
 def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="direct", solver_tol=0.0,
           solver_maxiter=None, solver_restart=30, warm_start=None, inner_rtol=None, real_projection=None,
-          inner_precision=64, group=None, engine=None, device=0, Q0=None, contour=None):
+          inner_precision=64, group=None, engine=None, device=0, Q0=None, contour=None, contour_policy=None):
     """feast(A, [B,] (Emin, Emax); M0, fpm, backend=:hip) for real-symmetric / Hermitian
     dense (numpy) or sparse (scipy) matrices.  Real input is complexified and the result is
     real.(q), exactly as feast_sygv!/feast_scsrgv! do (src/dense/feast_dense.jl:362-387).
@@ -105,6 +105,7 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         raise ValueError("Matrix B must be Hermitian positive definite")
     Emin, Emax = float(interval[0]), float(interval[1])
     fpm = feastinit() if fpm is None else fpm
+    aspect_unset = int(fpm[18]) == FEAST_UNINITIALIZED      # the caller left the contour shape to the library
     feastdefault(fpm)
     N = A.shape[0]
     M0 = min(int(M0), N)
@@ -130,13 +131,19 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
             substituted = {"requested": "direct", "used": solver, "warm_start": bool(warm_start),
                            "inner_rtol": inner_rtol, "solver_maxiter": int(solver_maxiter)}
             _warn_substitution(substituted)
+            # inexact solves pay for a sharper filter than they can use: unless the caller fixed fpm[18], the driver
+            # picks the ellipse ratio itself (hip_backend.feast_hip_hermitian, contour_policy)
+            if contour_policy is None and aspect_unset and contour is None and warm_start and inner_rtol is not None:
+                contour_policy = "auto"
+                substituted["contour_policy"] = "auto"
     warm_start = bool(warm_start)                 # an explicitly named iterative solver keeps the reference's zero guess
     solver_maxiter = 500 if solver_maxiter is None else int(solver_maxiter)
     eng = _engine(engine, device)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,
-                              inner_precision=inner_precision, group=group, Q0=Q0, contour=contour)
+                              inner_precision=inner_precision, group=group, Q0=Q0, contour=contour,
+                              contour_policy=contour_policy)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
     if real_input:

@@ -203,3 +203,67 @@ def split_balanced_assignment(costs, nw, ncols=64, min_cols=16, max_heavy=3):
     rest = [e for e in range(ne) if e not in heavy]
     light_lists, _ = lpt(rest, nw - k)
     return [(list(heavy), g, k) for g in range(k)] + [(nodes, 0, 1) for nodes in light_lists]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Contour policy for INEXACT shifted solves (not in the reference; used when `solver=:direct` on large sparse input
+# maps to the batched Krylov solvers, api.py).  With exact solves the contraction of FEAST's subspace iteration per
+# refinement loop is the filter ratio rho(lambda_{M0+1}) / rho(lambda_inside) -- 1e-5 and better for a 16-point Gauss
+# rule on the circle.  With inner solves that only reduce the residual by `inner_rtol` per loop the contraction is
+# max(filter ratio, inner_rtol): a filter sharper than inner_rtol is paid for (its nodes sit next to the real axis,
+# where the shifted systems are worst conditioned) and never used.  The policy therefore picks the TALLEST ellipse
+# (fpm[18], the reference's own parameter: src/core/feast_parameters.jl:232-247, src/core/feast_tools.jl:212-284)
+# whose filter still separates the subspace from the rest of the spectrum by the factor the inner solves deliver.
+# ------------------------------------------------------------------------------------------------------------------
+ASPECT_CANDIDATES = (100, 150, 200, 300, 400, 600, 800, 1200, 1600, 2400, 3200, 4000, 5000, 6000, 8000)
+
+
+def filter_values(Zne, Wne, lam):
+    """rho(lambda) = Re sum_e 2 w_e / (z_e - lambda): the rational filter of the half contour with the real projection
+    (src/parallel/feast_parallel.jl:38-55 take the real part; weight 2 w_e: src/dense/feast_dense.jl:174)."""
+    lam = np.atleast_1d(np.asarray(lam, dtype=np.float64))
+    return np.real((2.0 * np.asarray(Wne)[None, :] / (np.asarray(Zne)[None, :] - lam[:, None])).sum(axis=1))
+
+
+def filter_ratio(Emin, Emax, ne, fpm16, aspect, d_rel, inside=None):
+    """Upper envelope of |rho| over |lambda - Emid| >= d_rel * r, divided by the smallest |rho| over the wanted
+    eigenvalues (`inside`: their current Ritz values; None: the whole interval, whose ends carry rho = 1/2)."""
+    fpm = np.zeros(65, dtype=np.int64)
+    fpm[2], fpm[16], fpm[18] = ne, fpm16, aspect
+    Zne, Wne = feast_contour(Emin, Emax, fpm)
+    r = 0.5 * (Emax - Emin)
+    mid = Emin + r
+    # the filter of a contour symmetric about Emid is symmetric about Emid: one side is enough.  Log-spaced out to
+    # 60 r, dense near the subspace edge where the envelope is decided.
+    d = d_rel * r * np.exp(np.linspace(0.0, math.log(60.0 / max(d_rel, 1e-3)) if d_rel < 60.0 else 0.0, 1500))
+    out = np.abs(filter_values(Zne, Wne, mid + d)).max()
+    pts = np.linspace(Emin, Emax, 257) if inside is None or len(inside) == 0 else np.asarray(inside, dtype=np.float64)
+    inn = np.abs(filter_values(Zne, Wne, pts)).min()
+    return float(out / max(inn, 1e-300))
+
+
+def choose_aspect(Emin, Emax, ne, fpm16, d_rel, target, inside=None, candidates=ASPECT_CANDIDATES):
+    """The largest fpm[18] among `candidates` whose filter_ratio is <= target; 100 (the reference's circle) when none
+    qualifies.  d_rel: where the first eigenvalue OUTSIDE the subspace is believed to lie, as a multiple of the
+    interval's half width measured from its midpoint."""
+    best = 100
+    for a in candidates:
+        if a >= 100 and filter_ratio(Emin, Emax, ne, fpm16, a, d_rel, inside) <= target:
+            best = max(best, a)
+    return int(best)
+
+
+def subspace_reach(ritz, Emin, Emax, quantile=0.8):
+    """How far the current subspace reaches beyond the interval, as a multiple of its half width measured from the
+    midpoint: the `quantile` point of the distances of the guard Ritz values (those outside [Emin, Emax]).  The
+    subspace holds the M0 eigen-directions with the largest filter values and the filter is symmetric about the
+    midpoint, so the first eigenvalue outside the subspace lies beyond the outermost guard on EITHER side; the
+    outermost guards are the least converged Ritz values (contaminated by far eigenvectors, they overshoot outward),
+    hence a quantile instead of the maximum.  None when there are no guards."""
+    ritz = np.asarray(ritz, dtype=np.float64)
+    r = 0.5 * (Emax - Emin)
+    mid = Emin + r
+    g = np.sort(np.abs(ritz[(ritz < Emin) | (ritz > Emax)] - mid))
+    if len(g) == 0:
+        return None
+    return float(g[min(len(g) - 1, int(quantile * len(g)))] / r)

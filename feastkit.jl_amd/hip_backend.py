@@ -29,8 +29,8 @@ import time
 import numpy as np
 import scipy.linalg as sla
 
-from .contour import (balanced_contour_points, cost_balanced_contour_points, distribute_contour_points, feast_contour, feast_gcontour,
-                      feast_inside_gcontour, split_balanced_assignment)
+from .contour import (balanced_contour_points, choose_aspect, cost_balanced_contour_points, distribute_contour_points, feast_contour,
+                      feast_gcontour, feast_inside_gcontour, split_balanced_assignment, subspace_reach)
 from .parameters import check_feast_srci_input, feast_tolerance, feastdefault
 from .types import FeastError, FeastResult
 
@@ -119,7 +119,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
                         preloaded=False, node_assignment="block", inner_precision=64, column_groups=1,
-                        spurious_filter=True):
+                        spurious_filter=True, contour_policy=None):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -147,6 +147,16 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
       feast_kernel.jl:183-186).  False keeps variant A's complex half-contour sum
       (feast_dense.jl:231), whose filter only decays like 1/distance: same converged
       eigenpairs, many more refinement loops.
+    contour_policy: None keeps fpm[18] as given (the reference's behaviour).  "auto" (inexact iterative solves with the
+      real projection only; ignored otherwise) lets the driver pick the ellipse ratio fpm[18] itself, loop by loop
+      (contour.choose_aspect): with inner solves that reduce the residual by inner_rtol per loop the contraction of a
+      refinement loop is max(filter ratio, ~2 inner_rtol), so among the candidate ratios the one minimising the
+      predicted work  a^-0.6 / ln(1 / max(filter ratio(a), 2 inner_rtol))  is taken (a^-0.6: measured fall of the
+      Krylov iterations per loop with the ratio a; a taller ellipse moves every node away from the spectrum).  The
+      filter ratio is evaluated at the reach of the current subspace (contour.subspace_reach of the Ritz values; loop 0:
+      the a-priori 1.4 half widths of a subspace 1.5 times the eigenvalue count).  Safeguard: when a loop contracts
+      the residual by less than 0.3 although the policy promised better, the ratio is halved for the next loops, down
+      to the reference's circle.
     """
     N = A.shape[0]
     feastdefault(fpm)
@@ -227,6 +237,34 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                               factor_precision=32, cache_factors=True)
         else:
             raise ValueError("inner_precision=32 needs the dense LU solver or the warm-started inexact iterative mode")
+    # -- contour policy (see the docstring): only where the filter is the real-projection filter and the solves are inexact
+    auto_contour = bool(contour_policy == "auto" and contour is None and inexact and real_projection and int(fpm[16]) in (0, 1))
+    policy = {"aspect": int(fpm[18]), "cap": 8000, "history": []}
+
+    def policy_pick(d_rel, inside_ritz=None):
+        """fpm[18] minimising the predicted work at subspace reach d_rel (capped by the safeguard)."""
+        import math as _m
+        from .contour import ASPECT_CANDIDATES, filter_ratio
+        floor_c = 2.0 * float(inner_rtol)
+        best, best_cost = 100, None
+        for a in ASPECT_CANDIDATES:
+            if a > policy["cap"]:
+                continue
+            c = max(filter_ratio(Emin, Emax, int(fpm[2]), int(fpm[16]), a, d_rel, inside_ritz), floor_c)
+            if c >= 0.5:
+                continue
+            cost = a ** -0.6 / _m.log(1.0 / c)
+            if best_cost is None or cost < best_cost:
+                best, best_cost = a, cost
+        return int(best)
+
+    if auto_contour:
+        fpm = fpm.copy()
+        fpm[18] = policy["aspect"] = policy_pick(1.4)
+        Zne, Wne = feast_contour(Emin, Emax, fpm)
+        engine.set_contour(Zne, Wne, 2.0)
+        engine.set_node_list(local_nodes)         # set_contour resets the node selection to "all"
+        policy["history"].append(policy["aspect"])
     t_setup = time.perf_counter() - t_setup
 
     if Q0 is not None and hasattr(Q0, "data_ptr"):
@@ -409,10 +447,25 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                                   factor_precision=inner_precision)
                 stats["inner_cap"] = inner_cap
                 eps_hist.clear()
+        if auto_contour:
+            # safeguard first: the policy promised a contraction of ~max(filter ratio, 2 inner_rtol) < 0.5 per loop
+            prev = stats["loops"][-2]["epsout"] if len(stats["loops"]) >= 2 else math.inf
+            if math.isfinite(prev) and math.isfinite(epsout) and epsout > 0.3 * prev and policy["aspect"] > 100:
+                policy["cap"] = max(100, policy["aspect"] // 2)
+            reach = subspace_reach(lam_sorted[:rank_q], Emin, Emax) if M > 0 else None
+            want = policy_pick(reach, lam_sorted[:M]) if reach is not None else min(policy["aspect"], policy["cap"])
+            if want != policy["aspect"]:
+                fpm[18] = policy["aspect"] = want
+                Zne, Wne = feast_contour(Emin, Emax, fpm)
+                engine.set_contour(Zne, Wne, 2.0)
+                engine.set_node_list(local_nodes)
+            policy["history"].append(policy["aspect"])
         active = rank_q
         dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
         ritz_lambda = lam_sorted.copy()
 
+    if auto_contour:
+        stats["contour_policy"] = {"fpm18_per_loop": policy["history"], "cap": policy["cap"]}
     if hasattr(engine, "set_column_mask"):
         engine.set_column_mask(None)
     if M_found == 0 and info == 0:

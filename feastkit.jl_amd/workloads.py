@@ -66,3 +66,65 @@ def disc_spectrum_general(N=8192, radius=33.05, coupling=0.05, seed=SEED):
         A -= 2 * np.outer(A @ v, v.conj())
         A -= 2 * np.outer(v, v.conj() @ A)
     return A, delta
+
+
+def _weighted_grid_laplacian(dims, weights):
+    """sum over grid edges (i, j) of w_ij (e_i - e_j)(e_i - e_j)^T plus Dirichlet boundary terms: the finite-volume
+    diffusion operator -div(k grad u) on a box grid (x fastest) with one conductivity per edge; symmetric positive
+    definite, same pattern as the constant-coefficient stencil.  weights[d] has the grid's shape with dims[d] + 1 along
+    axis d (edge to the lower neighbour / the boundary on either end)."""
+    import scipy.sparse as sp
+    n = int(np.prod(dims))
+    idx = np.arange(n).reshape(dims[::-1])             # idx[z, y, x] (or [y, x]): x fastest
+    diag = np.zeros(n)
+    rows, cols, vals = [], [], []
+    nd = len(dims)
+    for d in range(nd):
+        ax = nd - 1 - d                                # numpy axis of grid direction d
+        w = weights[d]
+        lo = np.take(w, range(0, dims[d]), axis=ax)    # edge below each cell
+        hi = np.take(w, range(1, dims[d] + 1), axis=ax)
+        diag += (lo + hi).ravel()
+        a = np.take(idx, range(0, dims[d] - 1), axis=ax).ravel()
+        b = np.take(idx, range(1, dims[d]), axis=ax).ravel()
+        wi = np.take(w, range(1, dims[d]), axis=ax).ravel()
+        rows += [a, b]
+        cols += [b, a]
+        vals += [-wi, -wi]
+    A = sp.coo_matrix((np.concatenate(vals + [diag]), (np.concatenate(rows + [np.arange(n)]), np.concatenate(cols + [np.arange(n)]))),
+                      shape=(n, n)).tocsr()
+    A.sort_indices()
+    return A
+
+
+def variable_coefficient_pencil(dims=(50, 40, 25), kind="diag_mass", seed=SEED, contrast=4.0):
+    """Pencils whose A and B do NOT commute (no closed-form spectrum; the tests take scipy's shift-invert Lanczos as
+    the CPU answer).  A = -div(k grad) on the box grid `dims` with a smooth-times-random conductivity per edge
+    (ratio up to `contrast`), Dirichlet boundary.
+      kind "diag_mass":  B = diag(rho), a random lumped mass matrix, rho in [1, contrast]
+      kind "stiff_mass": B = I + 0.1 * (a second, independently weighted diffusion operator): same pattern as A, SPD
+      kind "identity":   B = None (standard problem)
+    Returns (A, B)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng([seed, len(dims), int(np.prod(dims)), {"diag_mass": 1, "stiff_mass": 2, "identity": 3}[kind]])
+    shape = tuple(dims[::-1])
+
+    def edge_weights():
+        ws = []
+        for d in range(len(dims)):
+            s = list(shape)
+            s[len(dims) - 1 - d] += 1
+            grids = np.meshgrid(*[np.linspace(0.0, 1.0, m) for m in s], indexing="ij")
+            smooth = 1.0 + 0.5 * sum(np.sin(2.0 * np.pi * (k + 1) * g + 0.7 * k) for k, g in enumerate(grids)) / len(grids)
+            ws.append(smooth * (1.0 + (contrast - 1.0) * rng.random(s)) / contrast * 2.0)
+        return ws
+    A = _weighted_grid_laplacian(dims, edge_weights())
+    n = A.shape[0]
+    if kind == "diag_mass":
+        B = sp.diags(1.0 + (contrast - 1.0) * rng.random(n)).tocsr()
+    elif kind == "stiff_mass":
+        B = sp.csr_matrix(sp.identity(n, format="csr") + 0.1 * _weighted_grid_laplacian(dims, edge_weights()))
+        B.sort_indices()
+    else:
+        B = None
+    return A, B
