@@ -225,19 +225,34 @@ def filter_values(Zne, Wne, lam):
     return np.real((2.0 * np.asarray(Wne)[None, :] / (np.asarray(Zne)[None, :] - lam[:, None])).sum(axis=1))
 
 
+_FILTER_TABLES = {}
+
+
+def _filter_table(ne, fpm16, aspect):
+    """(Zne, Wne) of the unit interval (-1, 1) and the outer envelope E(d) = max_{d' >= d} |rho(d')| on a log-spaced
+    grid 1 <= d <= 60 (d in half widths from the midpoint).  The filter is invariant under shift and scaling of the
+    interval and symmetric about its midpoint for these contours, so one table per (ne, fpm16, aspect) serves every
+    solve; it is computed once per process."""
+    key = (int(ne), int(fpm16), int(aspect))
+    tab = _FILTER_TABLES.get(key)
+    if tab is None:
+        fpm = np.zeros(65, dtype=np.int64)
+        fpm[2], fpm[16], fpm[18] = ne, fpm16, aspect
+        Zne, Wne = feast_contour(-1.0, 1.0, fpm)
+        d = np.exp(np.linspace(0.0, math.log(60.0), 4000))
+        env = np.maximum.accumulate(np.abs(filter_values(Zne, Wne, d))[::-1])[::-1]
+        tab = _FILTER_TABLES[key] = (Zne, Wne, d, env)
+    return tab
+
+
 def filter_ratio(Emin, Emax, ne, fpm16, aspect, d_rel, inside=None):
     """Upper envelope of |rho| over |lambda - Emid| >= d_rel * r, divided by the smallest |rho| over the wanted
     eigenvalues (`inside`: their current Ritz values; None: the whole interval, whose ends carry rho = 1/2)."""
-    fpm = np.zeros(65, dtype=np.int64)
-    fpm[2], fpm[16], fpm[18] = ne, fpm16, aspect
-    Zne, Wne = feast_contour(Emin, Emax, fpm)
+    Zne, Wne, d, env = _filter_table(ne, fpm16, aspect)
     r = 0.5 * (Emax - Emin)
     mid = Emin + r
-    # the filter of a contour symmetric about Emid is symmetric about Emid: one side is enough.  Log-spaced out to
-    # 60 r, dense near the subspace edge where the envelope is decided.
-    d = d_rel * r * np.exp(np.linspace(0.0, math.log(60.0 / max(d_rel, 1e-3)) if d_rel < 60.0 else 0.0, 1500))
-    out = np.abs(filter_values(Zne, Wne, mid + d)).max()
-    pts = np.linspace(Emin, Emax, 257) if inside is None or len(inside) == 0 else np.asarray(inside, dtype=np.float64)
+    out = env[min(len(d) - 1, int(np.searchsorted(d, max(d_rel, 1.0), side="left")))]
+    pts = np.linspace(-1.0, 1.0, 65) if inside is None or len(inside) == 0 else (np.asarray(inside, dtype=np.float64) - mid) / r
     inn = np.abs(filter_values(Zne, Wne, pts)).min()
     return float(out / max(inn, 1e-300))
 

@@ -151,12 +151,12 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
       real projection only; ignored otherwise) lets the driver pick the ellipse ratio fpm[18] itself, loop by loop
       (contour.choose_aspect): with inner solves that reduce the residual by inner_rtol per loop the contraction of a
       refinement loop is max(filter ratio, ~2 inner_rtol), so among the candidate ratios the one minimising the
-      predicted work  a^-0.6 / ln(1 / max(filter ratio(a), 2 inner_rtol))  is taken (a^-0.6: measured fall of the
+      predicted work  a^-0.6 / ln(1 / max(filter ratio(a), inner_rtol))  is taken (a^-0.6: measured fall of the
       Krylov iterations per loop with the ratio a; a taller ellipse moves every node away from the spectrum).  The
       filter ratio is evaluated at the reach of the current subspace (contour.subspace_reach of the Ritz values; loop 0:
       the a-priori 1.4 half widths of a subspace 1.5 times the eigenvalue count).  Safeguard: when a loop contracts
-      the residual by less than 0.3 although the policy promised better, the ratio is halved for the next loops, down
-      to the reference's circle.
+      the residual by less than 0.3 although the policy promised better, then -- if inner solves stopped at the iteration
+      cap -- the cap is doubled, else the ratio is halved for the next loops, down to the reference's circle.
     """
     N = A.shape[0]
     feastdefault(fpm)
@@ -241,19 +241,18 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     auto_contour = bool(contour_policy == "auto" and contour is None and inexact and real_projection and int(fpm[16]) in (0, 1))
     policy = {"aspect": int(fpm[18]), "cap": 8000, "history": []}
 
-    def policy_pick(d_rel, inside_ritz=None):
-        """fpm[18] minimising the predicted work at subspace reach d_rel (capped by the safeguard)."""
-        import math as _m
+    def policy_pick(d_rel, inside_ritz=None, limit=None):
+        """fpm[18] minimising the predicted work at subspace reach d_rel (capped by the safeguard and by `limit`)."""
         from .contour import ASPECT_CANDIDATES, filter_ratio
-        floor_c = 2.0 * float(inner_rtol)
+        floor_c = float(inner_rtol)
         best, best_cost = 100, None
         for a in ASPECT_CANDIDATES:
-            if a > policy["cap"]:
+            if a > policy["cap"] or (limit is not None and a > limit):
                 continue
             c = max(filter_ratio(Emin, Emax, int(fpm[2]), int(fpm[16]), a, d_rel, inside_ritz), floor_c)
             if c >= 0.5:
                 continue
-            cost = a ** -0.6 / _m.log(1.0 / c)
+            cost = a ** -0.6 / math.log(1.0 / c)
             if best_cost is None or cost < best_cost:
                 best, best_cost = a, cost
         return int(best)
@@ -448,24 +447,45 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                 stats["inner_cap"] = inner_cap
                 eps_hist.clear()
         if auto_contour:
-            # safeguard first: the policy promised a contraction of ~max(filter ratio, 2 inner_rtol) < 0.5 per loop
+            # Safeguard first.  The policy promised a contraction of max(filter ratio, inner_rtol) < 0.5 per loop.  When a
+            # loop delivers less than 0.3 there are two possible culprits: inner solves that stopped at the iteration
+            # cap before reaching inner_rtol (status 5 on some node: a taller ellipse would only HELP them -- raise the
+            # cap instead), or a filter that is too soft for this spectrum (lower the ellipse, down to the circle).
             prev = stats["loops"][-2]["epsout"] if len(stats["loops"]) >= 2 else math.inf
-            if math.isfinite(prev) and math.isfinite(epsout) and epsout > 0.3 * prev and policy["aspect"] > 100:
-                policy["cap"] = max(100, policy["aspect"] // 2)
-            reach = subspace_reach(lam_sorted[:rank_q], Emin, Emax) if M > 0 else None
-            want = policy_pick(reach, lam_sorted[:M]) if reach is not None else min(policy["aspect"], policy["cap"])
+            if math.isfinite(prev) and math.isfinite(epsout) and epsout > 0.3 * prev:
+                if int(np.max(status)) == 5 and inner_cap < 16 * solver_maxiter:
+                    inner_cap *= 2
+                    engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
+                                      factor_precision=inner_precision)
+                    stats["inner_cap"] = inner_cap
+                    eps_hist.clear()
+                elif policy["aspect"] > 100:
+                    policy["cap"] = max(100, policy["aspect"] // 2)
+            # Steering: the filter model evaluated at the reach of the subspace.  The guard Ritz values overshoot outward
+            # while they are far from converged (measured on four 50 000-unknown pencils: apparent reach 5-15 half widths
+            # after loop 0, 2-4 while the wanted pairs pass 1e-3, within 2 % of the first eigenvalue outside the subspace
+            # late), hence a cautious quantile of their distances early, nearly the outermost one later, and never more
+            # than double the ratio in one loop.  Five steering rules were measured on those pencils (this one; the same
+            # gated on epsout < 1e-2; outermost guard with one notch per loop; acting only on a reach that two loops
+            # agree on; a feedback rule on the observed contraction): all land within 10 % of each other and 3-9 times
+            # ahead of the circle -- the early over-estimates cost little because an early loop on a taller ellipse is
+            # also a cheaper loop; this rule had the best geometric mean.
+            reach = subspace_reach(lam_sorted[:rank_q], Emin, Emax, 0.8 if not (epsout < 1e-2) else 0.95) if M > 0 else None
+            want = (policy_pick(reach, lam_sorted[:M], limit=2 * policy["aspect"]) if reach is not None
+                    else min(policy["aspect"], policy["cap"]))
             if want != policy["aspect"]:
                 fpm[18] = policy["aspect"] = want
                 Zne, Wne = feast_contour(Emin, Emax, fpm)
                 engine.set_contour(Zne, Wne, 2.0)
                 engine.set_node_list(local_nodes)
             policy["history"].append(policy["aspect"])
+            policy.setdefault("reach", []).append(None if reach is None else round(reach, 3))
         active = rank_q
         dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
         ritz_lambda = lam_sorted.copy()
 
     if auto_contour:
-        stats["contour_policy"] = {"fpm18_per_loop": policy["history"], "cap": policy["cap"]}
+        stats["contour_policy"] = {"fpm18_per_loop": policy["history"], "cap": policy["cap"], "reach": policy.get("reach")}
     if hasattr(engine, "set_column_mask"):
         engine.set_column_mask(None)
     if M_found == 0 and info == 0:

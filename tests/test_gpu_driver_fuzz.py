@@ -155,9 +155,10 @@ def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
 
 
 @pytest.mark.parametrize("seed,cases", [(21, 6)])
-@pytest.mark.parametrize("prec", [64, 32])
-def test_inexact_mode_fuzz(engine, seed, cases, prec):
-    """The bench's mode (COCG, Ritz warm start, inner_rtol 3e-2, <= 100 iterations per loop; fp64 and complex64
+@pytest.mark.parametrize("prec,policy", [(64, None), (32, None), (64, "auto")])
+def test_inexact_mode_fuzz(engine, seed, cases, prec, policy=None):
+    """policy="auto": the contour policy of the default call (the driver picks fpm[18] loop by loop) on the same pencils.
+    The bench's mode (COCG, Ritz warm start, inner_rtol 3e-2, <= 100 iterations per loop; fp64 and complex64
     correction panels) on random sparse symmetric pencils: no oracle counterpart for the loop count (inexact solves), so
     the bar is the answer -- all eigenvalues of the interval to 1e-9, residuals <= 1e-10 recomputed on the host."""
     rng = np.random.default_rng(seed)
@@ -169,8 +170,9 @@ def test_inexact_mode_fuzz(engine, seed, cases, prec):
         kind, A, B, Ad, Bd, want, Emin, Emax, M0 = c
         fpm = fk.feastinit(); fpm[2] = 8; fpm[4] = 60
         got = fk.feast(A, B, (Emin, Emax), M0=M0, fpm=fpm, engine=engine, solver="cocg", warm_start=True, inner_rtol=3e-2,
-                       solver_maxiter=100, inner_precision=prec)
-        tag = f"seed={seed} case={done} kind={kind} N={Ad.shape[0]} gen={B is not None} k={len(want)} M0={M0} prec={prec}"
+                       solver_maxiter=100, inner_precision=prec, contour_policy=policy)
+        tag = f"seed={seed} case={done} kind={kind} N={Ad.shape[0]} gen={B is not None} k={len(want)} M0={M0} prec={prec} policy={policy}"
+        assert (policy is None) == ("contour_policy" not in got.stats), tag
         assert got.info == 0 and got.M == len(want), f"{tag}: info {got.info} M {got.M} loop {got.loop} eps {got.epsout:.1e}"
         assert np.abs(np.sort(got.lambda_) - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), tag
         BX = got.q if Bd is None else Bd @ got.q

@@ -230,6 +230,39 @@ def test_cfg3_reference_default_call_full_size(engine):
     assert not np.iscomplexobj(r.q)
     _cfg3_check(r, A, B, inside)
     assert r.loop <= 12
+    # fpm[18] was left unset: the driver chose the ellipse ratio itself (contour policy), taller than the circle
+    pol = r.stats["contour_policy"]["fpm18_per_loop"]
+    assert r.stats["solver_substitution"]["contour_policy"] == "auto" and min(pol) > 100 and len(pol) == r.loop + 1
+    # a caller who SETS fpm[18] (even to the reference's default value) keeps it: the reference's contour, the reference's answer
+    rc = fk.feast(A, B, (0.0, 0.1775), M0=64, fpm=fpm_with(f2=16, f18=100), engine=engine)
+    _cfg3_check(rc, A, B, inside)
+    assert "contour_policy" not in rc.stats
+    assert rc.stats["krylov_iterations"] > 2 * r.stats["krylov_iterations"]      # what the policy is for
+
+
+_PENCILS = {"diag_mass_3d": ((50, 40, 25), "diag_mass"), "stiff_mass_3d": ((50, 40, 25), "stiff_mass"), "diag_mass_2d": ((250, 200), "diag_mass")}
+
+
+@pytest.mark.parametrize("name", sorted(_PENCILS))
+def test_default_call_noncommuting_pencils_full_size(engine, name):
+    """The default call beyond cfg 3: three N = 50 000 pencils whose A and B do NOT commute (variable-coefficient
+    diffusion operators in 3-D and 2-D with a random lumped mass matrix or a second, independently weighted operator as
+    B; no closed-form spectrum).  CPU answer: scipy's shift-invert Lanczos (ARPACK + SuperLU) on the same matrices.
+    feast(A, B, (Emin, Emax); M0=64, fpm[2]=16) must return every eigenvalue of the interval with residuals
+    recomputed on the host <= 1e-11, with the contour policy engaged."""
+    import scipy.sparse.linalg as spla
+    dims, kind = _PENCILS[name]
+    A, B = fk.workloads.variable_coefficient_pencil(dims, kind)
+    assert abs(A @ B - B @ A).max() > 1.0                       # far from commuting
+    w = np.sort(spla.eigsh(A, k=48, M=B, sigma=0.0, which="LM", return_eigenvectors=False, tol=1e-12))
+    Emax = 0.5 * (w[43] + w[44])
+    r = fk.feast(A, B, (0.0, Emax), M0=64, fpm=fpm_with(f2=16, f4=40), engine=engine)
+    assert r.info == 0 and r.M == 44 and r.epsout <= 1e-12, (r.info, r.M, r.epsout, r.loop)
+    assert np.abs(np.sort(r.lambda_) - w[:44]).max() <= 1e-9 * w[43]
+    res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0) / np.linalg.norm(r.q, axis=0)
+    assert res.max() <= 1e-11
+    pol = r.stats["contour_policy"]["fpm18_per_loop"]
+    assert min(pol) > 100 and r.loop <= 16
 
 
 @pytest.mark.parametrize("aspect,cap", [(4000, 50), (100, 100)])

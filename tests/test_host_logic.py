@@ -464,3 +464,63 @@ def test_split_balanced_assignment_covers_every_node_column_pair_once():
     lay8 = split_balanced_assignment(cfg3, 8)
     assert lay8[0] == ([15], 0, 2) and lay8[1] == ([15], 1, 2)                          # node 15: 399 of 1630, fair share 204
     assert all(k == 1 for _n, _g, k in split_balanced_assignment(cfg3, 4))               # 399 ~ fair share of 4: no split
+
+
+def test_contour_policy_filter_model():
+    """contour.filter_values / filter_ratio / choose_aspect / subspace_reach: the filter of the half contour with the real
+    projection is ~1 inside, 1/2 at the interval ends, decays outside; it is invariant under shift and scaling of the
+    interval; the envelope ratio falls with the distance and rises with the ellipse ratio."""
+    from feastkit_jl_amd import contour as ct
+    fpm = fk.feastinit(); fpm[2] = 16
+    fk.feastdefault(fpm)
+    Z, W = fk.feast_contour(2.0, 6.0, fpm)
+    f = ct.filter_values(Z, W, np.array([2.0, 3.0, 4.0, 5.5, 6.0, 6.6, 8.0, 20.0, -3.0]))
+    assert np.allclose(f[[1, 2, 3]], 1.0, atol=1e-6) and np.allclose(f[[0, 4]], 0.5, atol=1e-6)
+    assert abs(f[5]) < 1e-3 and abs(f[6]) < 1e-8 and abs(f[7]) < 1e-12 and abs(f[8]) < 1e-10
+    # scale / shift invariance of the ratio, monotone in the distance, growing with the ellipse ratio
+    for a in (100, 800, 4000):
+        r1 = ct.filter_ratio(2.0, 6.0, 16, 0, a, 1.5)
+        r2 = ct.filter_ratio(-0.3, 0.1, 16, 0, a, 1.5)
+        assert abs(r1 / r2 - 1.0) < 1e-9
+        assert ct.filter_ratio(2.0, 6.0, 16, 0, a, 1.2) >= r1 >= ct.filter_ratio(2.0, 6.0, 16, 0, a, 2.5)
+    assert ct.filter_ratio(0, 1, 16, 0, 100, 1.5) < ct.filter_ratio(0, 1, 16, 0, 800, 1.5) < ct.filter_ratio(0, 1, 16, 0, 8000, 1.5)
+    # the envelope is an upper bound of the filter beyond d
+    fpm[18] = 2400
+    Z, W = fk.feast_contour(0.0, 2.0, fpm)
+    lam = 1.0 + np.linspace(1.5, 40.0, 3000)
+    inn = np.abs(ct.filter_values(Z, W, np.linspace(0.0, 2.0, 65))).min()
+    assert np.abs(ct.filter_values(Z, W, lam)).max() / inn <= ct.filter_ratio(0.0, 2.0, 16, 0, 2400, 1.5) * (1 + 1e-6)
+    # choose_aspect: the tallest candidate under the target; the circle when nothing qualifies
+    a = ct.choose_aspect(0.0, 1.0, 16, 0, 1.5, 0.06)
+    assert a >= 1600 and ct.filter_ratio(0.0, 1.0, 16, 0, a, 1.5) <= 0.06
+    assert ct.choose_aspect(0.0, 1.0, 16, 0, 1.5, 1e-12) == 100
+    assert ct.choose_aspect(0.0, 1.0, 16, 0, 1.1, 0.03) < ct.choose_aspect(0.0, 1.0, 16, 0, 2.0, 0.03)
+    # subspace_reach: guards only, measured from the midpoint in half widths
+    ritz = np.array([0.2, 0.5, 0.9, 1.3, 1.6, -0.4, 2.0])
+    assert ct.subspace_reach(ritz, 0.0, 1.0, 1.0) == pytest.approx(3.0)
+    assert ct.subspace_reach(ritz, 0.0, 1.0, 0.0) == pytest.approx(1.6)
+    assert ct.subspace_reach(np.array([0.2, 0.5]), 0.0, 1.0) is None
+
+
+def test_contour_policy_driver_host_logic():
+    """feast_hip_hermitian(contour_policy="auto") on the test engine: the policy engages only for inexact warm-started
+    iterative solves with the real projection, leaves the caller's fpm untouched, records its choices, and the answer is
+    the oracle's.  (The stand-in engine solves exactly, so this checks the control flow, not the speed.)"""
+    import scipy.sparse as sp
+    from oracle_engine import OracleEngine
+    A, B, lam = fo.cfg3_problem(10, 8, 6)
+    inside = lam[(lam >= 0.0) & (lam <= 0.8)]
+    fpm = fk.feastinit(); fpm[2] = 8
+    keep = fpm.copy()
+    r = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 0.8, 24, fpm, solver="cocg", warm_start=True, inner_rtol=3e-2,
+                               solver_maxiter=100, contour_policy="auto")
+    fk.feastdefault(keep)
+    assert np.array_equal(fpm, keep)                                     # the caller's array only got its defaults
+    assert r.info == 0 and r.M == len(inside) and np.abs(np.sort(r.lambda_) - inside).max() < 1e-10
+    pol = r.stats["contour_policy"]
+    assert len(pol["fpm18_per_loop"]) >= 1 and all(100 <= a <= 8000 for a in pol["fpm18_per_loop"]) and pol["fpm18_per_loop"][0] > 100
+    # not engaged: direct solver / no warm start / explicit contour / complex Hermitian input
+    for kw in (dict(solver="direct"), dict(solver="cocg", warm_start=False), dict(solver="cocg", warm_start=True, inner_rtol=3e-2,
+               contour=fk.feast_contour(0.0, 0.8, keep))):
+        r2 = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 0.8, 24, keep.copy(), contour_policy="auto", **kw)
+        assert r2.info == 0 and r2.M == len(inside) and "contour_policy" not in r2.stats

@@ -20,8 +20,8 @@ for seed in range(first, first + n):
         elif which == "general":
             t.test_general_driver_fuzz_vs_oracle(eng, seed, cases)
         else:
-            for prec in (64, 32):
-                t.test_inexact_mode_fuzz(eng, seed, cases, prec)
+            for prec, policy in ((64, None), (32, None), (64, "auto")):
+                t.test_inexact_mode_fuzz(eng, seed, cases, prec, policy)
         print("seed", seed, "ok", flush=True)
     except AssertionError as ex:
         bad += 1

@@ -32,9 +32,12 @@ for tag in which:
     A, B, Emin, Emax, want = problem(tag)
     eng.set_problem(A, B)
     Q0 = eng.upload(fk.seeded_subspace(A.shape[0], M0))
+    only = os.environ.get("EXP_RUNS")
     runs = [("circle cap100", dict(f18=100, cap=100)), ("a=4000 cap50", dict(f18=4000, cap=50)), ("a=2400 cap50", dict(f18=2400, cap=50)),
             ("auto cap100", dict(policy="auto", cap=100)), ("auto cap50", dict(policy="auto", cap=50))]
     for name, kw in runs:
+        if only and not any(name.startswith(o) for o in only.split(",")):
+            continue
         best, out = 1e9, None
         for rep in range(2):
             fpm = fk.feastinit()
