@@ -156,7 +156,7 @@ def test_general_driver_fuzz_vs_oracle(engine, seed, cases):
 
 @pytest.mark.parametrize("seed,cases", [(21, 6)])
 @pytest.mark.parametrize("prec,policy", [(64, None), (32, None), (64, "auto")])
-def test_inexact_mode_fuzz(engine, seed, cases, prec, policy=None):
+def test_inexact_mode_fuzz(engine, seed, cases, prec, policy):
     """policy="auto": the contour policy of the default call (the driver picks fpm[18] loop by loop) on the same pencils.
     The bench's mode (COCG, Ritz warm start, inner_rtol 3e-2, <= 100 iterations per loop; fp64 and complex64
     correction panels) on random sparse symmetric pencils: no oracle counterpart for the loop count (inexact solves), so
