@@ -240,7 +240,7 @@ def test_cfg3_reference_default_call_full_size(engine):
     assert rc.stats["krylov_iterations"] > 2 * r.stats["krylov_iterations"]      # what the policy is for
 
 
-_PENCILS = {"diag_mass_3d": ((50, 40, 25), "diag_mass"), "stiff_mass_3d": ((50, 40, 25), "stiff_mass"), "diag_mass_2d": ((250, 200), "diag_mass")}
+_PENCILS = {"diag_mass_3d": ((50, 40, 25), "diag_mass"), "stiff_mass_3d": ((50, 40, 25), "stiff_mass"), "diag_mass_2d": ((400, 125), "diag_mass")}
 
 
 @pytest.mark.parametrize("name", sorted(_PENCILS))
@@ -254,6 +254,7 @@ def test_default_call_noncommuting_pencils_full_size(engine, name):
     dims, kind = _PENCILS[name]
     A, B = fk.workloads.variable_coefficient_pencil(dims, kind)
     assert abs(A @ B - B @ A).max() > 1.0                       # far from commuting
+    assert fk.api._sparse_direct_solver(A, B, 16) == "krylov"   # (a 250 x 200 grid would be a band narrow enough for the banded LU)
     w = np.sort(spla.eigsh(A, k=48, M=B, sigma=0.0, which="LM", return_eigenvectors=False, tol=1e-12))
     Emax = 0.5 * (w[43] + w[44])
     r = fk.feast(A, B, (0.0, Emax), M0=64, fpm=fpm_with(f2=16, f4=40), engine=engine)
