@@ -37,11 +37,12 @@ EMIN, EMAX, M0, NE = 0.0, 0.1775, 64, 16
 
 
 def kernel_source_hash():
-    """sha256 over the sources of the Krylov kernels the roofline object is about (fh_sparse.hip and the headers it
-    includes): PMC traffic files record it, a file whose kernels have changed since is not quoted."""
+    """sha256 over the sources of the Krylov kernels the roofline object is about (fh_sparse.hip, the headers it
+    includes, and fh_api.hip, which owns their launch geometry): PMC traffic files record it, a file whose kernels or
+    launches have changed since is not quoted."""
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "feastkit.jl_amd", "csrc")
-    for name in ("fh_sparse.hip", "fh_common.hpp", "fh_kernels.hpp"):
+    for name in ("fh_sparse.hip", "fh_api.hip", "fh_common.hpp", "fh_kernels.hpp"):
         hsh.update(open(os.path.join(d, name), "rb").read())
     return hsh.hexdigest()[:16]
 
@@ -345,15 +346,21 @@ def main():
     matrix_bytes = nnz * (4 + 8 + 8) + 4 * (N + 1)            # col idx + A,B values (f64) + row pointers
     cands = [roof("spmm", "k_spmm<cplx,double,64,false>", node_launches * matrix_bytes + col_passes * N * 16)]
     if args.solver == "cocg":
-        _, p_launches = eng.profile_get("cocg_p")
-        cands.append(roof("cocg_xr", "k_cocg_update<cplx,64>", upd_cols * 3 * N * 16))
-        # direction update P = R + beta P (3 passes per active column) + the shared accumulator (read + write per launch)
-        cands.append(roof("cocg_p", "k_cocg_p_sum<cplx,64>", upd_cols * 3 * N * 16 + p_launches * 2 * N * 64 * 16))
+        _, v_launches = eng.profile_get("cocg_vec")
+        if v_launches:
+            # fused vector kernel: r (read + write), q (read), p (read + write) per stepping column + the shared
+            # accumulator (read + write per launch)
+            cands.append(roof("cocg_vec", "k_fused_vec<cplx,64,true>", upd_cols * 5 * N * 16 + v_launches * 2 * N * 64 * 16))
+        else:                                                     # FH_COCG_FUSED=0: the five-launch iteration
+            _, p_launches = eng.profile_get("cocg_p")
+            cands.append(roof("cocg_xr", "k_cocg_update<cplx,64>", upd_cols * 3 * N * 16))
+            # direction update P = R + beta P (3 passes per active column) + the shared accumulator (read + write per launch)
+            cands.append(roof("cocg_p", "k_cocg_p_sum<cplx,64>", upd_cols * 3 * N * 16 + p_launches * 2 * N * 64 * 16))
     else:
         cands.append(roof("bicg_xr", "k_xr_update<cplx,64>", upd_cols * 7 * N * 16))
     cands = sorted([r for r in cands if r], key=lambda r: -r["share_of_step"])
     classes = {}
-    for cls in ("spmm", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz",
+    for cls in ("spmm", "cocg_vec", "cocg_xr", "cocg_p", "bicg_xr", "bicg_p", "bicg_s", "dot_finalize", "ortho", "gram", "accumulate", "ritz",
                 "reduced_eig", "allreduce"):
         ms, n = eng.profile_get(cls)
         if n:

@@ -638,7 +638,7 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         static const bool no_lds = getenv("FH_NO_LDS_SPMM") != nullptr;
         // (the LDS-window kernel keeps its active-node list in a 64-entry LDS array: wider node batches -- trapezoid
         //  contours put no bound on fpm[2] -- take the gather kernel, which has no such limit)
-        const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds && c.nodes <= 64;
+        const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds && c.nodes <= 64 && c.dot_mode != 6;   // (fused-COCG dots: gather kernel only)
         a.nblk_rows = h->csr.nblk; a.blk_start = h->csr.blk_start; a.ext_ptr = h->csr.ext_ptr; a.ext_idx = h->csr.ext_idx;
         a.lcol = lds_kernel ? h->csr.lcol : nullptr;
         fh_prof_begin(h, "spmm");
@@ -751,17 +751,35 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     s.active = (int*)p; s.iters = s.active + nl; s.status = s.iters + nl; s.node_active = s.status + nl;
     int* d_count = s.node_active + nodes;
     cplx* d_wnode = nullptr;
-    if (sum_acc) {
+    // Fused COCG iteration (fh_sparse.hip): SpMM with five dots -> one finalize -> one vector kernel.  CSR operator through
+    // the gather kernel only; FH_COCG_FUSED=0 selects the five-launch form for comparison.
+    static const bool fused_off = getenv("FH_COCG_FUSED") && atoi(getenv("FH_COCG_FUSED")) == 0;
+    const bool fused = method == 1 && h->kind == 2 && !fused_off;
+    if (sum_acc || fused) {
         s.accum = d_count + 4; s.node_accum = s.accum + nl;
         FH_CHECK(hipMemsetAsync(s.accum, 0, (nl + nodes) * sizeof(int), h->stream));
+    }
+    if (sum_acc) {
         if ((rc = fh_upload_coefs(h, "kry_wnode", *wnode, &d_wnode))) return rc;
     }
     const int nblk_op = fh_op_nblk(h, ld);
     const int nblk_vec = fh_kry_nblk(N, ld, nodes);
-    const int nblk_max = std::max(nblk_op, nblk_vec);
+    int fv_blk = 0, fv_seg = 0, fv_per = 0;
+    if (fused) fh_fused_vec_geometry(N, ld, &fv_blk, &fv_seg, &fv_per);
+    const int nblk_max = std::max(std::max(nblk_op, nblk_vec), fv_blk * fv_seg);
     if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
     cplx* part1 = (cplx*)p;
     cplx* part2 = part1 + (size_t)nodes * nblk_max * ld;
+    cplx* sp[2] = {nullptr, nullptr};
+    unsigned long long* d_tickets = nullptr;
+    if (fused) {
+        const size_t one = (size_t)nodes * nblk_op * ld;
+        if ((rc = fh_get_buf(h, "kry_partials_op", 2 * one * sizeof(cplx), &p))) return rc;
+        for (int q = 0; q < 2; ++q) sp[q] = (cplx*)p + q * one;
+        if ((rc = fh_get_buf(h, "kry_tickets", (size_t)nodes * sizeof(unsigned long long), &p))) return rc;
+        d_tickets = (unsigned long long*)p;
+        FH_CHECK(hipMemsetAsync(d_tickets, 0, (size_t)nodes * sizeof(unsigned long long), h->stream));
+    }
 
     // shifted-operator coefficients: S_e = z_e B - A
     std::vector<cplx> ca(nl), cb(nl);
@@ -892,6 +910,19 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                 fh_prof_begin(h, "dot_finalize"); fh_launch_fin_rho(fa, ld, nodes, h->stream); fh_prof_end(h);
                 fh_prof_begin(h, "bicg_p"); fh_launch_p_update(va, ld, nblk_vec, nodes, h->stream); fh_prof_end(h);
                 res.op_calls += 2;
+            } else if (fused) {
+                // Q = S P (stored in V), sigma = p^T q, kappa = q^T q (fh_sparse.hip, fused COCG)
+                oc.X = P; oc.Y = V; oc.U = nullptr; oc.dot_mode = 6; oc.node_active = s.node_active;
+                oc.partial1 = sp[0]; oc.partial2 = sp[1];
+                fh_fused_fin_args ff;
+                ff.s = s; ff.sig = sp[0]; ff.kap = sp[1];
+                ff.rho = part1; ff.rr = part2; ff.tickets = d_tickets; ff.final_check = 0;
+                ff.predict_stop = (h->rtol >= 1e-3 && h->atol == 0.0) ? 1 : 0;
+                ff.nblk_op = fh_apply_operator(h, ld, oc);
+                ff.nblk_vec = (it + k == 0) ? fa.nblk : fv_blk * fv_seg;      // first iteration: the init kernel's partial rows
+                fh_prof_begin(h, "dot_finalize"); fh_launch_fused_fin(ff, ld, nodes, h->stream); fh_prof_end(h);
+                fh_prof_begin(h, "cocg_vec"); fh_launch_fused_vec(va, ld, h->stream); fh_prof_end(h);
+                res.op_calls += 1;
             } else {
                 // Q = S P (stored in V), sigma = p^T S p
                 oc.X = P; oc.Y = V; oc.U = nullptr; oc.dot_mode = 4; oc.node_active = s.node_active;
@@ -935,6 +966,13 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                 }
             }
         }
+    }
+    if (fused && it > 0) {
+        // the stop test of the last step: true norms from the last vector kernel's partials (no SpMM follows it)
+        fh_fused_fin_args ff;
+        ff.s = s; ff.sig = ff.kap = nullptr; ff.rho = part1; ff.rr = part2; ff.tickets = d_tickets;
+        ff.nblk_op = 0; ff.nblk_vec = fv_blk * fv_seg; ff.final_check = 1; ff.predict_stop = 0;
+        fh_launch_fused_fin(ff, ld, nodes, h->stream);
     }
     FH_CHECK(hipStreamSynchronize(h->stream));
     if (getenv("FH_DEBUG_TIMING"))

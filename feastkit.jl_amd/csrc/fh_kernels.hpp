@@ -68,6 +68,21 @@ void fh_launch_sum_finish(const cplx* src, const cplx* rho, const cplx* acc, cpl
 void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_p(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 void fh_launch_cocg_p_sum(const fh_vec_args& a, int ld, int nodes, hipStream_t st);
+// ---- fused COCG iteration (fh_sparse.hip, "fused COCG"): SpMM with five dots -> one finalize -> one vector kernel --------
+struct fh_fused_fin_args {
+    fh_krylov_scalars s;
+    const cplx *sig, *kap;                    // SpMM partials [nodes][nblk_op][LD]: p^T q, q^T q (unconjugated)
+    const cplx *rho, *rr;                     // partials of the last vector kernel / the init kernel [nodes][nblk_vec][LD]: r^T r, |r|^2
+    int nblk_op, nblk_vec;
+    unsigned long long* tickets;              // [nodes], zero between launches
+    int final_check;                          // 1: only re-evaluate the stop test from (rho, rr) after the last step
+    int predict_stop;                         // inexact solves: also stop on the predicted norm of the next residual
+};
+void fh_launch_fused_fin(const fh_fused_fin_args& a, int ld, int nodes, hipStream_t st);
+// geometry of the fused vector kernel for a panel of N x ld elements: blocks per segment, segments, elements per thread
+void fh_fused_vec_geometry(int N, int ld, int* nblk, int* nseg, int* per_thread);
+// R -= alpha Q, [ACC += w alpha P | X += alpha P], P = R + beta P, partials r^T r and |r|^2 ([nodes][nblk*nseg][LD])
+void fh_launch_fused_vec(const fh_vec_args& a, int ld, hipStream_t st);
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_alpha(const fh_fin_args& a, int ld, int nodes, hipStream_t st);
 void fh_launch_fin_omega(const fh_fin_args& a, int ld, int nodes, hipStream_t st);

@@ -40,6 +40,7 @@ __device__ __forceinline__ void fh_block_reduce_cols(cplx v, cplx* red, cplx* ou
 //            2: partial1 = <Y, Xown>, partial2 = <Y, Y>   (omega = <t,s>/<t,t>)
 //            3: partial2 = <Y, Y>                 (residual norms)
 //            4: partial1 = Xown^T Y  (unconjugated; COCG sigma = p^T S p)
+//            6: fused COCG: partial1 = p^T q, partial2 = q^T q (both unconjugated)   with p = Xown, q = Y
 //
 // Locality design (measured on cfg 3 with rocprofv3 FETCH_SIZE: a one-row-per-wave kernel
 // over all 64 columns re-fetched every gathered X row ~5x from beyond L2 -- 5.2 GB per launch
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
             }
             CT acc = fh_czero<CT>();
             CT xown = fh_czero<CT>();
-            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4) xown = X[(size_t)i * LD + c];
+            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4 || a.dot_mode == 6) xown = X[(size_t)i * LD + c];
             if (BIDENT) acc = cmul(cb, xown);            // B = I contributes cb * x_i
             for (int kb = k0; kb < k1; kb += 16) {
                 if (kb != k0) {                          // rows longer than 16 nonzeros: load on demand
@@ -244,11 +245,14 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 d2.x += cabs2(accd);
             } else if (a.dot_mode == 4) {
                 d1 = cadd(d1, cmul(to_d(xown), accd));   // unconjugated p^T (S p), COCG
+            } else if (a.dot_mode == 6) {
+                d1 = cadd(d1, cmul(to_d(xown), accd));   // p^T q
+                d2 = cadd(d2, cmul(accd, accd));         // q^T q (unconjugated)
             }
         }
         if (a.dot_mode != 0) {
             // per-column block reduction: 16 threads (4 waves x 4 row groups) share a column
-            if (a.dot_mode == 1 || a.dot_mode == 2 || a.dot_mode == 4) {
+            if (a.dot_mode == 1 || a.dot_mode == 2 || a.dot_mode == 4 || a.dot_mode == 6) {
                 red[t] = d1;
                 __syncthreads();
                 if (t < 16) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 }
                 __syncthreads();
             }
-            if (a.dot_mode == 2 || a.dot_mode == 3) {
+            if (a.dot_mode == 2 || a.dot_mode == 3 || a.dot_mode == 6) {
                 red[t] = d2;
                 __syncthreads();
                 if (t < 16) {
@@ -1089,6 +1093,267 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_p_sum(fh_vec_args a) {
 }
 
 // ------------------------------------------------------------------------------------
+// Fused COCG iteration: three launches per iteration (SpMM, one finalize, one vector kernel) instead of five, one global
+// reduction point instead of two, and one panel pass fewer (the residual is read and written once per iteration, not twice).
+//
+//   k_spmm (dot_mode 6)   q = S p,  sigma = p^T q,  kappa = q^T q
+//   k_fused_fin           alpha = rho / sigma with the TRUE rho = r^T r (summed from the previous vector kernel's partials);
+//                         rho of the NEXT residual is predicted from the recurrence r' = r - alpha q and the conjugacy
+//                         r^T q = p^T q:      rho' = alpha^2 kappa - rho,      beta = rho' / rho
+//   k_fused_vec           r -= alpha q;  ACC += w alpha p (sum mode) or x += alpha p;  p = r + beta p;  partials of the
+//                         TRUE r^T r and |r|^2 of the new residual for the next finalize
+//
+// Why this is safe: x += alpha p, r -= alpha (S p) keeps r = b - S x for ANY alpha and beta, so the residual that is tested
+// is always the residual of the iterate; alpha uses the true rho, only beta sees the prediction, and an inexact beta costs
+// conjugacy, not correctness.  (Measured before building it, numpy on 14 400-unknown pencils: iterations to 3e-2 / 1e-4 /
+// 1e-8 / 1e-12 are 133 / 299 / 381 / 480 with the true beta and 133 / 299 / 391 / 489 with the predicted one on the
+// hardest circle node, identical on every other node and on the tall ellipse.)  A first version streamed r through the
+// SpMM as well (r^T q, q^H r, |q|^2: exact rho' and the norm of r' one step ahead): the extra pass cost the gather kernel
+// 34 us per launch, more than the two launches it removed.
+// The stop test runs on the TRUE norm of the previous vector kernel, i.e. one SpMM late.  With inexact solves
+// (rtol >= 1e-3) a column also stops when the predicted |rho'| -- scaled by the current ratio |r|^2 / |r^T r| -- is below
+// target^2.  That estimate of |r'|^2 is exact when the residuals are complex multiples of real vectors (real right-hand
+// side and B = I or B a polynomial in A: cfg 3), and was measured within a factor 0.5 .. 2.4 (median 1.00) of the true
+// norm on a pencil whose A and B do not commute: it saves the SpMM of the last iteration of a node (10 % of the SpMM
+// node passes of a cfg-3 solve) at the price of stopping a few columns at up to twice the inexact target.
+// ------------------------------------------------------------------------------------
+#define FH_FV_THREADS 512
+#define FH_FV_EMAX 28
+
+void fh_fused_vec_geometry(int N, int ld, int* nblk, int* nseg, int* per_thread) {
+    const size_t total = (size_t)N * ld;
+    size_t g = (total + FH_FV_THREADS - 1) / FH_FV_THREADS;
+    if (g > 256) g = 256;                              // one 512-thread workgroup per CU (2 waves/SIMD, 256 VGPRs): 256 partial rows per node
+    if (g < 1) g = 1;
+    size_t e = (total + g * FH_FV_THREADS - 1) / (g * FH_FV_THREADS);
+    size_t segs = 1;
+    if (e > FH_FV_EMAX) { segs = (e + FH_FV_EMAX - 1) / FH_FV_EMAX; e = (total + g * FH_FV_THREADS * segs - 1) / (g * FH_FV_THREADS * segs); }
+    *nblk = (int)g; *nseg = (int)segs; *per_thread = (int)e;
+}
+
+template <int LD>
+__global__ __launch_bounds__(FH_FIN_BLOCK) void k_fused_fin(fh_fused_fin_args a) {
+    // grid (LD / 16, nodes): one workgroup sums the partial rows of one 16-column tile of one node.  64 row groups x 16
+    // columns; every thread has all its loads in flight at once (the rows were written by other XCDs: each load is a
+    // trip to the Infinity Cache), summed in a fixed order.
+    __shared__ double red[FH_FIN_BLOCK / 64][16][8];
+    __shared__ int cnt_active, cnt_accum;
+    const int node = blockIdx.y, tile = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int c16 = lane & 15, g = wave * 4 + (lane >> 4);   // 64 row groups x 16 columns
+    const int c = tile * 16 + c16;
+    const int i = node * LD + c;
+    if (a.s.node_active[node] == 0) {                   // (node_active is only rewritten by the node's LAST tile workgroup, at its end)
+        if (!a.final_check) {
+            if (t < 16) a.s.accum[i] = 0;
+            if (tile == 0 && t == 0) a.s.node_accum[node] = 0;
+        }
+        return;
+    }
+    if (t == 0) { cnt_active = 0; cnt_accum = 0; }
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.0;
+    {
+        const size_t base = (size_t)node * a.nblk_vec * LD + c;
+#pragma unroll 4
+        for (int b = g; b < a.nblk_vec; b += 64) {
+            const cplx r1 = a.rho[base + (size_t)b * LD], r2 = a.rr[base + (size_t)b * LD];
+            v[0] += r1.x; v[1] += r1.y; v[2] += r2.x;
+        }
+    }
+    if (!a.final_check) {
+        const size_t base = (size_t)node * a.nblk_op * LD + c;
+#pragma unroll 4
+        for (int b = g; b < a.nblk_op; b += 64) {
+            const size_t o = base + (size_t)b * LD;
+            const cplx s1 = a.sig[o], s3 = a.kap[o];
+            v[3] += s1.x; v[4] += s1.y; v[5] += s3.x; v[6] += s3.y;
+        }
+    }
+    // the four row groups of a wave (lanes c16, c16 + 16, + 32, + 48), then the 16 waves through LDS in a fixed order
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        v[q] += __shfl_xor(v[q], 16);
+        v[q] += __shfl_xor(v[q], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) red[wave][lane][q] = v[q];
+    }
+    __syncthreads();
+    if (t < 16) {
+        double w[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            double sacc = red[0][t][q];
+#pragma unroll
+            for (int k = 1; k < FH_FIN_BLOCK / 64; ++k) sacc += red[k][t][q];
+            w[q] = sacc;
+        }
+        int stepped = 0;
+        if (a.s.active[i]) {
+            const cplx rho = cmake(w[0], w[1]);
+            const double rr = w[2];
+            const double rn = sqrt(rr);
+            a.s.rnorm[i] = rn;
+            a.s.rho[i] = rho;
+            int act = 1;
+            // non-finite first: `!(NaN > target)` is true and would mark a NaN residual as converged
+            if (!isfinite(rn)) { act = 0; a.s.status[i] = 8; }
+            else if (!(rn > a.s.target[i])) { act = 0; a.s.status[i] = 0; }       // the true norm says: converged
+            else if (!a.final_check) {
+                const cplx sigma = cmake(w[3], w[4]), kappa = cmake(w[5], w[6]);
+                const cplx al = cdiv(rho, sigma);
+                if (cabs2(sigma) == 0.0 || cabs2(rho) == 0.0 || !fh_finite(al)) {
+                    act = 0; a.s.status[i] = 8;                                   // breakdown
+                } else {
+                    const cplx rho_next = csub(cmul(cmul(al, al), kappa), rho);
+                    const cplx beta = cdiv(rho_next, rho);
+                    a.s.alpha[i] = al;
+                    a.s.iters[i] += 1;
+                    stepped = 1;
+                    const double tg = a.s.target[i];
+                    // |r'|^2 estimated as |rho'| * (|r|^2 / |r^T r|); inexact mode only (see the header of this section)
+                    const double rr_next = sqrt(cabs2(rho_next)) * (rr / sqrt(cabs2(rho)));
+                    if (a.predict_stop && rr_next <= tg * tg && rr_next >= 1e-12 * rr) {
+                        act = 0; a.s.status[i] = 0;
+                        a.s.rnorm[i] = sqrt(rr_next);
+                        a.s.beta[i] = cmake(0, 0);
+                    } else if (!fh_finite(beta)) {
+                        act = 0; a.s.status[i] = 8;
+                        a.s.beta[i] = cmake(0, 0);
+                    } else {
+                        a.s.beta[i] = beta;
+                    }
+                }
+            }
+            a.s.active[i] = act;
+            if (act) atomicAdd(&cnt_active, 1);
+        }
+        if (!a.final_check) {
+            a.s.accum[i] = stepped;
+            if (stepped) atomicAdd(&cnt_accum, 1);
+        }
+    }
+    __syncthreads();
+    // Per-node counters are sums over the LD / 16 tile workgroups: ONE returning 64-bit atomic per tile carries
+    // (active columns << 40 | stepping columns << 20 | 1 ticket); the workgroup that draws the last ticket knows both
+    // totals from the value returned and publishes node_active / node_accum (read by the NEXT kernels only).  Integer
+    // arithmetic: the order of arrival does not matter.
+    if (t == 0) {
+        unsigned long long* scratch = a.tickets + node;
+        const unsigned long long mine = ((unsigned long long)cnt_active << 40) | ((unsigned long long)cnt_accum << 20) | 1ull;
+        const unsigned long long old = atomicAdd(scratch, mine);
+        if ((old & 0xFFFFFull) == (unsigned long long)gridDim.x - 1ull) {
+            const unsigned long long tot = old + mine;
+            a.s.node_active[node] = (int)(tot >> 40);
+            if (!a.final_check) a.s.node_accum[node] = (int)((tot >> 20) & 0xFFFFFull);
+            atomicExch(scratch, 0ull);
+        }
+    }
+}
+
+template <typename CT, int LD, bool SUM>
+__global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, int per_thread) {
+    // grid (nblk, nseg).  A thread OWNS per_thread (<= 28) elements of the panel, G * 512 apart (a multiple of LD: one
+    // column per thread), for every node: the weighted steps of all nodes are summed in registers and the shared
+    // accumulator is read and written once per launch.  One workgroup per CU at two waves per SIMD: the register file
+    // holds the 28 accumulators beside twelve 16-byte loads in flight per thread (96 KiB per CU, three times what the
+    // HBM latency needs).
+    __shared__ double red[FH_FV_THREADS / 64][LD][3];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c = t % LD;
+    const size_t total = (size_t)a.N * LD;
+    const size_t stride = (size_t)gridDim.x * FH_FV_THREADS;
+    const size_t e0 = (size_t)blockIdx.y * stride * per_thread + (size_t)blockIdx.x * FH_FV_THREADS + t;
+    const int prow = blockIdx.y * gridDim.x + blockIdx.x, nprow = gridDim.x * gridDim.y;
+    cplx acc[FH_FV_EMAX];
+#pragma unroll
+    for (int j = 0; j < FH_FV_EMAX; ++j) acc[j] = cmake(0, 0);
+    bool any = false;
+    for (int n = 0; n < a.nodes; ++n) {
+        if (!a.s.node_accum[n]) continue;                       // uniform over the grid: nobody writes a partial row
+        const int i = n * LD + c;
+        const bool step = a.s.accum[i] != 0;
+        const bool act = a.s.active[i] != 0;
+        if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) atomicAdd(a.counters + 2, (unsigned long long)a.s.node_accum[n]);
+        double d1x = 0.0, d1y = 0.0, d2 = 0.0;
+        if (step) {
+            any = true;
+            const CT alpha = cvt<CT>(a.s.alpha[i]);
+            const CT beta = cvt<CT>(a.s.beta[i]);
+            cplx coef = cmake(0, 0);
+            if (SUM) {
+                coef = cmul(a.wnode[n], a.s.alpha[i]);
+                if (a.sum_scale) { const double sc = a.sum_scale[i]; coef.x *= sc; coef.y *= sc; }
+            }
+            const CT* __restrict__ Q = (const CT*)a.V + (size_t)n * a.node_stride;
+            CT* __restrict__ R = (CT*)a.R + (size_t)n * a.node_stride;
+            CT* __restrict__ P = (CT*)a.P + (size_t)n * a.node_stride;
+            CT* __restrict__ X = SUM ? nullptr : (CT*)a.X + (size_t)n * a.node_stride;
+#pragma unroll
+            for (int j0 = 0; j0 < FH_FV_EMAX; j0 += 4) {
+                if (j0 >= per_thread) break;
+                CT pv[4], qv[4], rv[4], xv[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t e = e0 + (size_t)(j0 + u) * stride;
+                    ok[u] = (j0 + u < per_thread) && e < total;
+                    pv[u] = fh_czero<CT>(); qv[u] = fh_czero<CT>(); rv[u] = fh_czero<CT>(); xv[u] = fh_czero<CT>();
+                    if (ok[u]) {
+                        pv[u] = P[e];
+                        if (act) { qv[u] = fh_ld_nt(Q + e); rv[u] = R[e]; }
+                        if (!SUM) xv[u] = X[e];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t e = e0 + (size_t)(j0 + u) * stride;
+                    if (SUM) cfma(acc[j0 + u], coef, to_d(pv[u]));
+                    else if (ok[u]) { cfma(xv[u], alpha, pv[u]); X[e] = xv[u]; }
+                    if (act && ok[u]) {
+                        const CT rn = csub(rv[u], cmul(alpha, qv[u]));
+                        R[e] = rn;
+                        P[e] = cadd(rn, cmul(beta, pv[u]));
+                        const cplx rd = to_d(rn);
+                        d1x += rd.x * rd.x - rd.y * rd.y; d1y += 2.0 * rd.x * rd.y; d2 += cabs2(rd);
+                    }
+                }
+            }
+        }
+        // per-column sums of the workgroup: lanes that share a column inside a wave first (LD < 64), then the 8 waves in
+        // a fixed order through LDS
+        if (LD < 64) {
+#pragma unroll
+            for (int off = LD; off < 64; off <<= 1) {
+                d1x += __shfl_xor(d1x, off); d1y += __shfl_xor(d1y, off); d2 += __shfl_xor(d2, off);
+            }
+        }
+        if (lane < LD) { red[wave][lane][0] = d1x; red[wave][lane][1] = d1y; red[wave][lane][2] = d2; }
+        __syncthreads();
+        if (t < LD) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < FH_FV_THREADS / 64; ++w) { s0 += red[w][t][0]; s1 += red[w][t][1]; s2 += red[w][t][2]; }
+            const size_t o = ((size_t)n * nprow + prow) * LD + t;
+            a.partial1[o] = cmake(s0, s1);
+            a.partial2[o] = cmake(s2, 0.0);
+        }
+        __syncthreads();
+    }
+    if (SUM && any) {
+#pragma unroll
+        for (int j = 0; j < FH_FV_EMAX; ++j) {
+            if (j >= per_thread) break;
+            const size_t e = e0 + (size_t)j * stride;
+            if (e < total) a.sum_acc[e] = cadd(a.sum_acc[e], acc[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 #define FH_DISPATCH_VEC(prec, ld, KERNEL, grid, st, args)                                          \
@@ -1182,4 +1447,29 @@ void fh_launch_widen_axpy(cplx* X, size_t x_stride, const cplxf* D, size_t d_str
     if (ld == 16) hipLaunchKernelGGL((k_widen_axpy<16>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, X, x_stride, D, d_stride, r0norm, total);
     else if (ld == 32) hipLaunchKernelGGL((k_widen_axpy<32>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, X, x_stride, D, d_stride, r0norm, total);
     else hipLaunchKernelGGL((k_widen_axpy<64>), dim3(nblk, nodes), dim3(FH_BLOCK), 0, st, X, x_stride, D, d_stride, r0norm, total);
+}
+
+void fh_launch_fused_fin(const fh_fused_fin_args& a, int ld, int nodes, hipStream_t st) {
+    if (ld == 16) hipLaunchKernelGGL((k_fused_fin<16>), dim3(1, nodes), dim3(FH_FIN_BLOCK), 0, st, a);
+    else if (ld == 32) hipLaunchKernelGGL((k_fused_fin<32>), dim3(2, nodes), dim3(FH_FIN_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_fused_fin<64>), dim3(4, nodes), dim3(FH_FIN_BLOCK), 0, st, a);
+}
+template <typename CT, int LD>
+static void launch_fused_vec_t(const fh_vec_args& a, dim3 grid, int per_thread, hipStream_t st) {
+    if (a.sum_acc) hipLaunchKernelGGL((k_fused_vec<CT, LD, true>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
+    else hipLaunchKernelGGL((k_fused_vec<CT, LD, false>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
+}
+void fh_launch_fused_vec(const fh_vec_args& a, int ld, hipStream_t st) {
+    int nblk, nseg, per;
+    fh_fused_vec_geometry(a.N, ld, &nblk, &nseg, &per);
+    const dim3 grid(nblk, nseg);
+    if (a.prec == 32) {
+        if (ld == 16) launch_fused_vec_t<cplxf, 16>(a, grid, per, st);
+        else if (ld == 32) launch_fused_vec_t<cplxf, 32>(a, grid, per, st);
+        else launch_fused_vec_t<cplxf, 64>(a, grid, per, st);
+    } else {
+        if (ld == 16) launch_fused_vec_t<cplx, 16>(a, grid, per, st);
+        else if (ld == 32) launch_fused_vec_t<cplx, 32>(a, grid, per, st);
+        else launch_fused_vec_t<cplx, 64>(a, grid, per, st);
+    }
 }
