@@ -344,7 +344,9 @@ def main():
     _, col_passes = eng.profile_get("spmm.column_passes")
     _, upd_cols = eng.profile_get("update.active_columns")
     matrix_bytes = nnz * (4 + 8 + 8) + 4 * (N + 1)            # col idx + A,B values (f64) + row pointers
-    cands = [roof("spmm", "k_spmm<cplx,double,64,false>", node_launches * matrix_bytes + col_passes * N * 16)]
+    # (full-width panels over a real matrix go through the row-per-wave kernel; FH_SPMM_ROW=0 selects k_spmm)
+    spmm_kernel = "k_spmm<cplx,double,64,false>" if os.environ.get("FH_SPMM_ROW") == "0" else "k_spmm_row<cplx,false,true>"
+    cands = [roof("spmm", spmm_kernel, node_launches * matrix_bytes + col_passes * N * 16)]
     if args.solver == "cocg":
         _, v_launches = eng.profile_get("cocg_vec")
         if v_launches:

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfeasthip.so")
+# FEASTHIP_LIB: another build of the same library (kernel experiments: tools/ scripts compare variants in one GPU session)
+LIB_PATH = os.environ.get("FEASTHIP_LIB") or os.path.join(_HERE, "libfeasthip.so")
 
 
 class FeastHipStats(C.Structure):

@@ -183,6 +183,10 @@ static void fh_free_problem(feasthip_ctx* h) {
     if (h->csr.aval) hipFree(h->csr.aval);
     if (h->csr.bval) hipFree(h->csr.bval);
     if (h->csr.perm) hipFree(h->csr.perm);
+    if (h->csr.rp8) hipFree(h->csr.rp8);
+    if (h->csr.col8) hipFree(h->csr.col8);
+    if (h->csr.a8) hipFree(h->csr.a8);
+    if (h->csr.b8) hipFree(h->csr.b8);
     if (h->csr.blk_start) hipFree(h->csr.blk_start);
     if (h->csr.ext_ptr) hipFree(h->csr.ext_ptr);
     if (h->csr.ext_idx) hipFree(h->csr.ext_idx);
@@ -439,6 +443,17 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
         }
         rowptr.swap(rp2); col.swap(col2); av.swap(av2); bv.swap(bv2);
     }
+    // The nonzero with the LARGEST column index goes first in its row.  k_spmm sweeps the rows in ascending order, so that
+    // is the X row nobody has touched yet (the one gather of a row that comes from HBM, not from L2): the kernel
+    // issues it one row step ahead (fh_sparse.hip).  The order inside a row means nothing else to any kernel.
+    for (int64_t i = 0; i < N; ++i) {
+        int kmax = rowptr[i];
+        for (int k = rowptr[i] + 1; k < rowptr[i + 1]; ++k) if (col[k] > col[kmax]) kmax = k;
+        if (kmax != rowptr[i]) {
+            std::swap(col[kmax], col[rowptr[i]]); std::swap(av[kmax], av[rowptr[i]]);
+            if (hasB) std::swap(bv[kmax], bv[rowptr[i]]);
+        }
+    }
     fh_csr& d = h->csr;
     d.N = N; d.nnz = (int64_t)col.size(); d.is_complex = sizeof(VT) == sizeof(cplx); d.b_identity = hasB ? 0 : 1;
     FH_CHECK(hipMalloc((void**)&d.rowptr, (N + 1) * sizeof(int)));
@@ -450,6 +465,31 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
     if (hasB) {
         FH_CHECK(hipMalloc(&d.bval, std::max<size_t>(1, col.size()) * sizeof(VT)));
         FH_CHECK(hipMemcpy(d.bval, bv.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
+    }
+    if (sizeof(VT) == sizeof(double)) {
+        // chunk-of-8 copy of the rows for k_spmm_row (fh_sparse.hip): one s_load_dwordx8 / x16 per chunk, no tail tests
+        std::vector<int> rp8(N + 1, 0);
+        for (int64_t i = 0; i < N; ++i) rp8[i + 1] = rp8[i] + (rowptr[i + 1] - rowptr[i] + 7) / 8;
+        const size_t n8 = (size_t)rp8[N] * 8;
+        std::vector<int> col8(std::max<size_t>(8, n8));
+        std::vector<double> a8(std::max<size_t>(8, n8), 0.0), b8(hasB ? std::max<size_t>(8, n8) : 0, 0.0);
+        const double* avd = (const double*)av.data();
+        const double* bvd = (const double*)bv.data();
+        for (int64_t i = 0; i < N; ++i) {
+            size_t w = (size_t)rp8[i] * 8;
+            for (int k = rowptr[i]; k < rowptr[i + 1]; ++k, ++w) { col8[w] = col[k]; a8[w] = avd[k]; if (hasB) b8[w] = bvd[k]; }
+            for (; w < (size_t)rp8[i + 1] * 8; ++w) col8[w] = (int)i;
+        }
+        FH_CHECK(hipMalloc((void**)&d.rp8, (N + 1) * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.col8, col8.size() * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.a8, a8.size() * sizeof(double)));
+        FH_CHECK(hipMemcpy(d.rp8, rp8.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.col8, col8.data(), col8.size() * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.a8, a8.data(), a8.size() * sizeof(double), hipMemcpyHostToDevice));
+        if (hasB) {
+            FH_CHECK(hipMalloc((void**)&d.b8, b8.size() * sizeof(double)));
+            FH_CHECK(hipMemcpy(d.b8, b8.data(), b8.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
     }
     if (!perm.empty()) {
         FH_CHECK(hipMalloc((void**)&d.perm, N * sizeof(int)));
@@ -641,9 +681,14 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds && c.nodes <= 64 && c.dot_mode != 6;   // (fused-COCG dots: gather kernel only)
         a.nblk_rows = h->csr.nblk; a.blk_start = h->csr.blk_start; a.ext_ptr = h->csr.ext_ptr; a.ext_idx = h->csr.ext_idx;
         a.lcol = lds_kernel ? h->csr.lcol : nullptr;
+        // full-width panels over a real matrix: the row-per-wave kernel (FH_SPMM_ROW=0: the 4-rows-per-wave gather kernel)
+        static const bool row_off = getenv("FH_SPMM_ROW") && atoi(getenv("FH_SPMM_ROW")) == 0;
+        a.use_row_kernel = (ld == 64 && !h->csr.is_complex && h->csr.rp8 && !lds_kernel && !row_off) ? 1 : 0;
+        a.rp8 = h->csr.rp8; a.col8 = h->csr.col8; a.a8 = h->csr.a8; a.b8 = h->csr.b8;
         fh_prof_begin(h, "spmm");
         fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, fh_spmm_grid(a.N, ld), h->stream);
         fh_prof_end(h);
+        if (a.use_row_kernel) return fh_spmm_row_grid(a.N);
         if (lds_kernel) return (8 / (ld / 16)) * fh_spmm_lds_slots(a.nblk_rows, ld);
         return fh_spmm_partials(a.N, ld);     // partial-sum rows per node
     }
@@ -664,7 +709,8 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
 static int fh_op_nblk(feasthip_ctx* h, int ld) {
     // (an upper bound is enough here: it sizes the partial-sum buffers; the row count used by the finalize kernels is what
     //  fh_apply_operator returns for the kernel it actually launched)
-    if (h->kind == 2) return std::max(fh_spmm_partials((int)h->csr.N, ld), h->csr.lcol ? (8 / (ld / 16)) * fh_spmm_lds_slots(h->csr.nblk, ld) : 0);
+    if (h->kind == 2) return std::max(std::max(fh_spmm_partials((int)h->csr.N, ld), ld == 64 ? fh_spmm_row_grid((int)h->csr.N) : 0),
+                                      h->csr.lcol ? (8 / (ld / 16)) * fh_spmm_lds_slots(h->csr.nblk, ld) : 0);
     return fh_dense_op_nblk((int)h->dense.N);
 }
 // row permutation of the panels (block order of a renumbered sparse matrix), or null

@@ -85,6 +85,9 @@ struct fh_csr {
     int* col = nullptr;      // nnz
     void* aval = nullptr;    // nnz x (double|cplx), A on the union pattern
     void* bval = nullptr;    // nnz x (double|cplx), B on the union pattern (null if identity)
+    // rows padded to whole chunks of 8 nonzeros for the row-per-wave SpMM (real values only): chunk range of row i is
+    // [rp8[i], rp8[i+1]); col8 / a8 / b8 hold 8 entries per chunk, padding = (own row, 0.0, 0.0)
+    int* rp8 = nullptr; int* col8 = nullptr; double* a8 = nullptr; double* b8 = nullptr;
     int* perm = nullptr;     // N: row/column renumbering applied at ingest, perm[internal] = caller's index (null: none)
     // row blocks of the renumbered matrix (LDS-window SpMM): block b = rows [blk_start[b], blk_start[b+1]) (<= FH_SPMM_R),
     // ext_idx[ext_ptr[b] .. ext_ptr[b+1]) = the distinct rows OUTSIDE the block its nonzeros touch (<= FH_SPMM_EXT kept),

@@ -19,11 +19,14 @@ struct fh_spmm_args {
     int m;                                    // active width when node_active is null
     int uniform_coef;                         // coefA/coefB identical for every column of a node
     int prec;                                 // 64 | 32
+    const int* rp8 = nullptr; const int* col8 = nullptr; const double* a8 = nullptr; const double* b8 = nullptr;   // chunk-of-8 rows (fh_csr)
+    int use_row_kernel = 0;                   // LD = 64 and real matrix values: k_spmm_row (one wave per row); partial rows = fh_spmm_row_grid(N)
     // row blocks of a renumbered matrix (fh_common.hpp: fh_csr); lcol == null: not renumbered, k_spmm serves
     int nblk_rows; const int* blk_start; const int* ext_ptr; const int* ext_idx; const unsigned short* lcol;
 };
 int fh_spmm_grid(int N, int ld);
 int fh_spmm_partials(int N, int ld);
+int fh_spmm_row_grid(int N);
 int fh_spmm_lds_slots(int nblk_rows, int ld);
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st);
 

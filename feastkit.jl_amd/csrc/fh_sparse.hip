@@ -179,9 +179,18 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
             ncol = colidx[k0n + l16]; na = aval[k0n + l16];
             if (!BIDENT) nb = bval[k0n + l16];
         }
+        // FAR GATHER, one row step ahead.  Ingest puts the nonzero with the largest column index first in its row
+        // (fh_api.hip): in an ascending sweep that is the one X row of the step that no workgroup has touched yet -- it
+        // comes from HBM, the other gathers from L1/L2 -- and a wave that waits for it every step keeps exactly one HBM
+        // request in flight (measured: 2.9 us per 4-row step whatever the row length, 2.0-2.5 TB/s algorithmic).  Slot 0 of
+        // the NEXT row is therefore gathered while this row is computed: issued after this row's own gathers, so the
+        // wait for those (vmcnt counts in issue order) leaves it in flight.
+        CT xfar = fh_czero<CT>();
+        if (i_first < row_hi) xfar = X[(size_t)fh_bc16(ncol, 0) * LD + c];
         for (int i = i_first; i < row_hi; i += band) {
             const int k0 = k0n, k1 = k1n;
             int mycol = ncol; VT mya = na, myb = nb;
+            const CT xfar_cur = xfar;
             // prefetch for the next row of this group
             k0n = k0nn; k1n = k1nn;
             if (i + 2 * band < row_hi) { k0nn = rowptr[i + 2 * band]; k1nn = rowptr[i + 2 * band + 1]; }
@@ -215,10 +224,20 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 for (int q0 = 0; q0 < 16; q0 += 8) {
                     if (q0 >= cnt) break;
                     CT xs[8];
+                    const bool head = (q0 == 0) && (kb == k0);          // slot 0 of the row arrived a step ago
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
+                        if (q == 0 && q0 == 0) {
+                            // (kb == k0 on the first trip of every lane: the branch is uniform)
+                            if (head) { xs[0] = xfar_cur; continue; }
+                        }
                         const int j = fh_bc16(mycol, q0 + q);
                         xs[q] = X[(size_t)j * LD + c];
+                    }
+                    if (head) {
+                        // next row's far gather: the youngest load of this step
+                        xfar = fh_czero<CT>();
+                        if (i + band < row_hi) xfar = X[(size_t)fh_bc16(ncol, 0) * LD + c];
                     }
                     if (a.uniform_coef) {
 #pragma unroll
@@ -233,6 +252,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                     }
                 }
             }
+            if (k1 == k0 && i + band < row_hi) xfar = X[(size_t)fh_bc16(ncol, 0) * LD + c];   // empty row: nothing issued above
             if (Bv) acc = csub(fh_ld_nt(Bv + (size_t)i * LD + c), acc);
             fh_st_nt(Y + (size_t)i * LD + c, acc);
             const cplx accd = to_d(acc);
@@ -272,6 +292,157 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 }
                 __syncthreads();
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Row-per-wave SpMM for full-width panels (LD = 64, real matrix values): one WAVE takes one matrix row, lane = column.
+//
+// Why a second gather kernel.  k_spmm gives every 16-lane group of a wave its own row, so column indices and values live
+// in VGPRs and reach the lanes of a row through 40 DPP broadcasts per row; with 64-bit address arithmetic per gather that
+// is ~550 VALU cycles per 4-row step and 122-128 VGPRs (4 waves per SIMD), and the wave waits for its one HBM gather
+// every step.  Here the whole wave works on ONE row, so everything about the row is wave-uniform: row bounds, column
+// indices, A and B values are SCALAR loads into SGPRs, the gather base address of each nonzero is SALU arithmetic, the
+// coefficient of an FMA is an SGPR operand (v_fma_f64 with the matrix value straight from the scalar file) and no lane
+// ever broadcasts anything.  The products are accumulated as u = A x and v = B x (real coefficient times complex value:
+// two FMAs each per nonzero) and combined once per row, y = cb v + ca u, with PER-LANE complex coefficients -- the same
+// kernel serves (z B - A) X, A X, B X and the residual with one coefficient pair per column.  VALU work per row drops to
+// the 32 FMAs of the products plus the dots.
+// Locality: XCD group g = blockIdx & 7 owns the row slice g; its workgroups sweep the slice as a moving band of
+// (workgroups per group) x 16 rows, so the X rows a band needs (band + the two stencil planes) stay in that XCD's L2 or,
+// for the far planes of a wide stencil, in the Infinity Cache.  Row order inside a row: the far gather (largest column,
+// first in its row: fh_api.hip ingest) is issued first so that it has the longest time to arrive.
+// ------------------------------------------------------------------------------------
+#ifndef FH_ROW_THREADS
+#define FH_ROW_THREADS 1024
+#endif
+// Measured (cfg 3, us per launch at 1 / 3 / 16 active nodes; k_spmm: 33.3 / 128.4 / 582.8):
+//   1024 threads, 4 waves/SIMD (121 VGPRs, no spills), 1 workgroup per CU:  36.5 / 120.6 / 510.9   <- default
+//    512 threads, 6 waves/SIMD ( 79 VGPRs, no spills), 3 per CU:            34.7 / 117.1 / 575.2
+//   8 waves/SIMD (64 VGPRs): 73-80 VGPRs spilled (the kernel arguments alone hold ~50 SGPRs):  50 / 137-145 / 565-630
+#ifndef FH_ROW_WAVES
+#define FH_ROW_WAVES 4                     // waves per SIMD the register budget is cut for
+#endif
+#ifndef FH_ROW_BLOCKS_MAX
+#define FH_ROW_BLOCKS_MAX 1                // resident workgroups per CU the grid is sized for
+#endif
+static inline int fh_spmm_row_groups(int N, int blocks_per_cu) {
+    (void)N;
+    return 32 * blocks_per_cu;                 // workgroups per XCD group: every CU of the XCD holds blocks_per_cu of them
+}
+
+__device__ __forceinline__ double fh_uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// UNIF: the coefficient pair is the same for every column (the shifted operator z B - A): it lives in SGPRs
+template <typename CT, bool BIDENT, bool UNIF>
+__global__ __launch_bounds__(FH_ROW_THREADS, FH_ROW_WAVES) void k_spmm_row(fh_spmm_args a) {
+    constexpr int LD = 64;
+    __shared__ double red[FH_ROW_THREADS / 64][64][4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // uniform: everything below it is SALU
+    constexpr int WPB = FH_ROW_THREADS / 64;
+    const int S = gridDim.x >> 3;
+    const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int slice_rows = (a.N + 7) / 8;
+    const int row_lo = min(a.N, grp * slice_rows);
+    const int row_hi = min(a.N, row_lo + slice_rows);
+    const int band = S * WPB;
+    // the matrix arrays are read-only for the whole launch: constant address space, so that a load with a wave-uniform
+    // address is a scalar load (s_load_dwordx8 / x16) into SGPRs instead of a vector load that every lane repeats
+    typedef const double __attribute__((address_space(4))) * cdptr;
+    typedef const int __attribute__((address_space(4))) * ciptr;
+    const cdptr a8 = (cdptr)a.a8;
+    const cdptr b8 = (cdptr)a.b8;
+    const ciptr rp8 = (ciptr)a.rp8;
+    const ciptr col8 = (ciptr)a.col8;
+    const int prow = blockIdx.x, nprow = gridDim.x;
+
+    for (int node = 0; node < a.nodes; ++node) {
+        const size_t pbase = ((size_t)node * nprow + prow) * LD;
+        if (a.node_active && a.node_active[node] == 0) {
+            if (a.dot_mode != 0 && threadIdx.x < LD) {
+                if (a.partial1) a.partial1[pbase + threadIdx.x] = cmake(0, 0);
+                if (a.partial2) a.partial2[pbase + threadIdx.x] = cmake(0, 0);
+            }
+            continue;
+        }
+        if (a.counters && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int cols = a.node_active ? a.node_active[node] : a.m;
+            const int passes = (a.dot_mode == 1 || a.Bvec) ? 3 : 2;
+            atomicAdd(a.counters + 0, 1ull);
+            atomicAdd(a.counters + 1, (unsigned long long)(cols * passes));
+        }
+        const CT* __restrict__ X = (const CT*)a.X + (size_t)node * a.x_node_stride;
+        CT* __restrict__ Y = (CT*)a.Y + (size_t)node * a.y_node_stride;
+        const CT* __restrict__ Bv = a.Bvec ? (const CT*)a.Bvec + (size_t)node * a.b_node_stride : nullptr;
+        const CT* __restrict__ U = a.U ? (const CT*)a.U + (size_t)node * a.u_node_stride : nullptr;
+        cplx ca = a.coefA[node * LD + lane];
+        cplx cb = a.coefB[node * LD + lane];
+        if (UNIF) { ca = cmake(fh_uniform(ca.x), fh_uniform(ca.y)); cb = cmake(fh_uniform(cb.x), fh_uniform(cb.y)); }
+        double d1x = 0.0, d1y = 0.0, d2x = 0.0, d2y = 0.0;
+        for (int i = row_lo + slot * WPB + wave; i < row_hi; i += band) {
+            const int c0 = rp8[i], c1 = rp8[i + 1];
+            double ux = 0.0, uy = 0.0, vx = 0.0, vy = 0.0;
+            CT xown = fh_czero<CT>();
+            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4 || a.dot_mode == 6) xown = (X + (size_t)i * LD)[lane];
+            for (int ch = c0; ch < c1; ++ch) {
+                const ciptr cc = col8 + (size_t)ch * 8;
+                const cdptr aa = a8 + (size_t)ch * 8;
+                CT xs[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const CT* __restrict__ rowp = X + (size_t)cc[q] * LD;        // uniform base: SALU
+                    xs[q] = rowp[lane];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const cplx x = to_d(xs[q]);
+                    const double av = aa[q];
+                    ux += av * x.x; uy += av * x.y;
+                    if (!BIDENT) {
+                        const double bv = (b8 + (size_t)ch * 8)[q];
+                        vx += bv * x.x; vy += bv * x.y;
+                    }
+                }
+            }
+            cplx u = cmake(ux, uy), v = cmake(vx, vy);
+            if (BIDENT) v = to_d(xown);
+            cplx accd = cadd(cmul(cb, v), cmul(ca, u));
+            if (Bv) accd = csub(to_d(fh_ld_nt((Bv + (size_t)i * LD) + lane)), accd);
+            const CT acc = cvt<CT>(accd);
+            fh_st_nt((Y + (size_t)i * LD) + lane, acc);
+            accd = to_d(acc);
+            if (a.dot_mode == 1) {
+                const cplx t1 = cmulc(to_d(fh_ld_nt((U + (size_t)i * LD) + lane)), accd);
+                d1x += t1.x; d1y += t1.y;
+            } else if (a.dot_mode == 2) {
+                const cplx t1 = cmulc(accd, to_d(xown));
+                d1x += t1.x; d1y += t1.y; d2x += cabs2(accd);
+            } else if (a.dot_mode == 3) {
+                d2x += cabs2(accd);
+            } else if (a.dot_mode == 4) {
+                const cplx t1 = cmul(to_d(xown), accd);
+                d1x += t1.x; d1y += t1.y;
+            } else if (a.dot_mode == 6) {
+                const cplx t1 = cmul(to_d(xown), accd), t2 = cmul(accd, accd);
+                d1x += t1.x; d1y += t1.y; d2x += t2.x; d2y += t2.y;
+            }
+        }
+        if (a.dot_mode != 0) {
+            // lane = column: the 16 waves of the workgroup hold 16 partial sums per column, added in wave order
+            red[wave][lane][0] = d1x; red[wave][lane][1] = d1y; red[wave][lane][2] = d2x; red[wave][lane][3] = d2y;
+            __syncthreads();
+            if (threadIdx.x < LD) {
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int w = 0; w < WPB; ++w) { s0 += red[w][threadIdx.x][0]; s1 += red[w][threadIdx.x][1]; s2 += red[w][threadIdx.x][2]; s3 += red[w][threadIdx.x][3]; }
+                if (a.partial1) a.partial1[pbase + threadIdx.x] = cmake(s0, s1);
+                if (a.partial2) a.partial2[pbase + threadIdx.x] = cmake(s2, s3);
+            }
+            __syncthreads();
         }
     }
 }
@@ -553,7 +724,33 @@ static void launch_spmm_ct(const fh_spmm_args& a, int ld, bool is_complex, bool 
         else launch_spmm_ld<CT, double, 64>(a, bident, nblk, st);
     }
 }
+// workgroups of the row-per-wave kernel: 8 XCD groups x (32 CUs x resident workgroups per CU), capped so that a band
+// step never exceeds the rows of a slice
+int fh_spmm_row_grid(int N) {
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spmm_row<cplx, false, true>, FH_ROW_THREADS, 0) != hipSuccess || n < 1) n = 1;
+        per_cu = n > FH_ROW_BLOCKS_MAX ? FH_ROW_BLOCKS_MAX : n;
+    }
+    int S = fh_spmm_row_groups(N, per_cu);
+    const int slice_rows = (N + 7) / 8, wpb = FH_ROW_THREADS / 64;
+    const int need = (slice_rows + wpb - 1) / wpb;           // workgroups that cover a slice in one band step
+    if (S > need) S = need < 1 ? 1 : need;
+    return 8 * S;
+}
+
 void fh_launch_spmm(const fh_spmm_args& a, int ld, bool is_complex, bool bident, int nblk, hipStream_t st) {
+    if (a.use_row_kernel) {                // LD = 64, real matrix values: one wave per row (k_spmm_row)
+        dim3 grid(fh_spmm_row_grid(a.N)), block(FH_ROW_THREADS);
+#define FH_ROW_LAUNCH(CT_, BI_) \
+        do { if (a.uniform_coef) hipLaunchKernelGGL((k_spmm_row<CT_, BI_, true>), grid, block, 0, st, a); \
+             else hipLaunchKernelGGL((k_spmm_row<CT_, BI_, false>), grid, block, 0, st, a); } while (0)
+        if (a.prec == 32) { if (bident) FH_ROW_LAUNCH(cplxf, true); else FH_ROW_LAUNCH(cplxf, false); }
+        else { if (bident) FH_ROW_LAUNCH(cplx, true); else FH_ROW_LAUNCH(cplx, false); }
+#undef FH_ROW_LAUNCH
+        return;
+    }
     if (a.prec == 64 && a.lcol) {          // renumbered matrix, complex128 panels: the LDS-window kernel
         if (is_complex) {
             if (ld == 16) launch_spmm_lds<cplx, 16>(a, bident, st);
