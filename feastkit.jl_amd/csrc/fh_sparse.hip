@@ -1465,6 +1465,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
     const size_t stride = (size_t)gridDim.x * FH_FV_THREADS;
     const size_t e0 = (size_t)blockIdx.y * stride * per_thread + (size_t)blockIdx.x * FH_FV_THREADS + t;
     const int prow = blockIdx.y * gridDim.x + blockIdx.x, nprow = gridDim.x * gridDim.y;
+    constexpr int GRP = sizeof(CT) == 8 ? 2 : 4;               // elements per thread in flight at once, 3 loads each (complex64 panels with 4: the compiler spills 90 VGPRs)
     cplx acc[FH_FV_EMAX];
 #pragma unroll
     for (int j = 0; j < FH_FV_EMAX; ++j) acc[j] = cmake(0, 0);
@@ -1490,12 +1491,12 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
             CT* __restrict__ P = (CT*)a.P + (size_t)n * a.node_stride;
             CT* __restrict__ X = SUM ? nullptr : (CT*)a.X + (size_t)n * a.node_stride;
 #pragma unroll
-            for (int j0 = 0; j0 < FH_FV_EMAX; j0 += 4) {
+            for (int j0 = 0; j0 < FH_FV_EMAX; j0 += GRP) {
                 if (j0 >= per_thread) break;
-                CT pv[4], qv[4], rv[4], xv[4];
-                bool ok[4];
+                CT pv[GRP], qv[GRP], rv[GRP], xv[GRP];
+                bool ok[GRP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GRP; ++u) {
                     const size_t e = e0 + (size_t)(j0 + u) * stride;
                     ok[u] = (j0 + u < per_thread) && e < total;
                     pv[u] = fh_czero<CT>(); qv[u] = fh_czero<CT>(); rv[u] = fh_czero<CT>(); xv[u] = fh_czero<CT>();
@@ -1506,7 +1507,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < GRP; ++u) {
                     const size_t e = e0 + (size_t)(j0 + u) * stride;
                     if (SUM) cfma(acc[j0 + u], coef, to_d(pv[u]));
                     else if (ok[u]) { cfma(xv[u], alpha, pv[u]); X[e] = xv[u]; }
