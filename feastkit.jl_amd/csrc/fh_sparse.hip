@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
             CT* __restrict__ X = SUM ? nullptr : (CT*)a.X + (size_t)n * a.node_stride;
 #pragma unroll
             for (int j0 = 0; j0 < FH_FV_EMAX; j0 += GRP) {
-                if (j0 >= per_thread) break;
+                if (j0 >= per_thread) continue;                      // (no break: the loop must unroll fully -- acc[] lives in registers)
                 CT pv[GRP], qv[GRP], rv[GRP], xv[GRP];
                 bool ok[GRP];
 #pragma unroll
@@ -1544,9 +1544,8 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
     if (SUM && any) {
 #pragma unroll
         for (int j = 0; j < FH_FV_EMAX; ++j) {
-            if (j >= per_thread) break;
             const size_t e = e0 + (size_t)j * stride;
-            if (e < total) a.sum_acc[e] = cadd(a.sum_acc[e], acc[j]);
+            if (j < per_thread && e < total) a.sum_acc[e] = cadd(a.sum_acc[e], acc[j]);
         }
     }
 }
