@@ -112,3 +112,30 @@ def test_bench_layout_ranks_match_single_rank(engine, tmp_path, world):
     assert res[0][2] <= 1e-12 and abs(int(res[0][3]) - one.loop) <= 2
     assert np.allclose(res[0][4:4 + n], inside, atol=1e-10)
     assert np.allclose(res[0][4:4 + n], np.sort(one.lambda_), atol=1e-10)
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_command_two_ranks_on_one_card(launcher):
+    """The command the driver's scaling run issues, at N = 2 on the one card of the test box (ranks share the device: the
+    library takes its shared-device transport): `python bench.py --gpus 2 ...` launching its own ranks, and the driver's
+    own form `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...`.  The JSON line must say
+    n_gpus == 2 and carry the full answer (44 / 44 eigenpairs, converged, residual <= 1e-10)."""
+    import json
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--headline-only"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900, text=True)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong"
+    assert d["eigenpairs"] == d["expected_eigenpairs"] == 44 and d["converged"] is True
+    assert d["max_residual"] <= 1e-10 and d["max_eigenvalue_error"] <= 1e-10
+    assert d["value"] > 0 and d["unit"] == "eigenpairs/s"
