@@ -99,10 +99,16 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         raise ValueError("Matrix A must be square")
     if B is not None and B.shape != A.shape:
         raise ValueError("Matrix B must match size of A")
-    if not _is_hermitian(A):
-        raise ValueError("Matrix A must be Hermitian")
-    if B is not None and not _is_hermitian(B):
-        raise ValueError("Matrix B must be Hermitian positive definite")
+    eng = _engine(engine, device)
+    # input checks and the pattern scan cost tens of milliseconds on a 50 000-unknown CSR pair (sparse transposes): a
+    # repeated call with the same matrices (content fingerprint, engine.py) skips them
+    fp = (HipEngine._fingerprint(A), HipEngine._fingerprint(B)) if sp.issparse(A) else None
+    known = fp is not None and fp[0] and fp[1] is not False and getattr(eng, "_checked", {}).get("fp") == fp
+    if not known:
+        if not _is_hermitian(A):
+            raise ValueError("Matrix A must be Hermitian")
+        if B is not None and not _is_hermitian(B):
+            raise ValueError("Matrix B must be Hermitian positive definite")
     Emin, Emax = float(interval[0]), float(interval[1])
     fpm = feastinit() if fpm is None else fpm
     aspect_unset = int(fpm[18]) == FEAST_UNINITIALIZED      # the caller left the contour shape to the library
@@ -115,7 +121,12 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
     if sp.issparse(A) and solver in ("direct", "lu"):
         # the reference's sparse default is UMFPACK; the :hip backend has a direct path for band
         # matrices (batched banded LU) and otherwise the batched Krylov solver (north_star)
-        solver = _sparse_direct_solver(A, B, int(fpm[2]))
+        if known and eng._checked.get("nodes") == int(fpm[2]):
+            solver = eng._checked["direct"]
+        else:
+            solver = _sparse_direct_solver(A, B, int(fpm[2]))
+            if fp is not None and fp[0] and fp[1] is not False:
+                eng._checked = {"fp": fp, "nodes": int(fpm[2]), "direct": solver}
         if solver == "dense":
             A, B, solver = _densify(A), _densify(B), "direct"
             substituted = {"requested": "direct", "used": "dense LU of the expanded matrix"}
@@ -138,7 +149,6 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
                 substituted["contour_policy"] = "auto"
     warm_start = bool(warm_start)                 # an explicitly named iterative solver keeps the reference's zero guess
     solver_maxiter = 500 if solver_maxiter is None else int(solver_maxiter)
-    eng = _engine(engine, device)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,

@@ -819,7 +819,13 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, i
 // one 256 B segment per 16 lanes) comes straight from global memory, once per k-step, and is reused by the four
 // column tiles; only the U block -- whose contiguous direction (k) is the wrong one for an MFMA operand -- goes
 // through LDS (transposed, XOR-swizzled store).  Same transposed product and super-tile order as k_lu_gemm.
-template <int KC, typename T>
+// M3 (complex128 only): the complex product with THREE real MFMA products per k-step instead of four (Karatsuba / "3M"):
+//     P1 += ur lr,  P2 += ui li,  P3 += (ur + ui)(lr + li);      Re = P1 - P2,  Im = P3 - P1 - P2
+// on three accumulator tiles per column tile; the operand sums cost five fp64 adds per k-step and wave against four
+// saved MFMAs.  The imaginary part of a product is then formed by cancellation (componentwise error eps (|ur| + |ui|)
+// (|lr| + |li|) instead of eps (|ur li| + |ui lr|)): normwise the update is as accurate as before -- the LU tests against
+// LAPACK hold at their tolerances -- which is the guarantee ZGEMM3M gives.  FH_LU_3M=0 selects the four-product form.
+template <int KC, typename T, bool M3>
 __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
                                                               int c1, int TR, int TC) {
     T* A = LUs[blockIdx.y];
@@ -848,9 +854,11 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, i
         for (int s = 0; s < KC / 4; ++s) ln[s] = (irow < r1) ? A[(size_t)(k0 + kc + 4 * s + lk) * N + irow] : LU_MK(0, 0);
     };
     fetch(0);
-    typename lu_el<T>::v4 re[4], im[4];
+    typename lu_el<T>::v4 re[4], im[4], p3[M3 ? 4 : 1];
 #pragma unroll
     for (int a = 0; a < 4; ++a) { re[a] = (typename lu_el<T>::v4){0, 0, 0, 0}; im[a] = re[a]; }
+#pragma unroll
+    for (int a = 0; a < (M3 ? 4 : 1); ++a) p3[a] = (typename lu_el<T>::v4){0, 0, 0, 0};
     T lc[KC / 4];
     auto stage = [&]() {
 #pragma unroll
@@ -867,14 +875,25 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, i
             T u[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) u[a] = Us[4 * s + lk][(16 * a + lr) ^ ((4 * s + lk) & 15)];
+            if (M3) {
+                // re[] holds P1, im[] holds P2, p3[] holds P3 until the epilogue
+                const auto lsum = lc[s].x + lc[s].y;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(u[a].x, lc[s].x, re[a]);
+                for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(u[a].x, lc[s].x, re[a]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].x, lc[s].y, im[a]);
+                for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].y, lc[s].y, im[a]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(-u[a].y, lc[s].y, re[a]);
+                for (int a = 0; a < 4; ++a) p3[a] = lu_el<T>::mfma(u[a].x + u[a].y, lsum, p3[a]);
+            } else {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].y, lc[s].x, im[a]);
+                for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(u[a].x, lc[s].x, re[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].x, lc[s].y, im[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) re[a] = lu_el<T>::mfma(-u[a].y, lc[s].y, re[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) im[a] = lu_el<T>::mfma(u[a].y, lc[s].x, im[a]);
+            }
         }
     };
     int kc = 0;
@@ -889,14 +908,20 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, i
     stage();
     __syncthreads();
     T cv[4][4];
+    auto load_c = [&]() {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = cc0 + 16 * a + lu_el<T>::mrow(lk, r);
-            cv[a][r] = (irow < r1 && c < c1) ? A[(size_t)c * N + irow] : LU_MK(0, 0);
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int c = cc0 + 16 * a + lu_el<T>::mrow(lk, r);
+                cv[a][r] = (irow < r1 && c < c1) ? A[(size_t)c * N + irow] : LU_MK(0, 0);
+            }
+    };
+    // (four-product form: the C tile is loaded under the last chunk's MFMAs; with the third accumulator set there are no
+    //  registers left for that -- 19 VGPRs spilled -- so the three-product form loads it after the last chunk)
+    if (!M3) load_c();
     mma();
+    if (M3) load_c();
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -904,8 +929,13 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, i
             const int c = cc0 + 16 * a + lu_el<T>::mrow(lk, r);
             if (irow < r1 && c < c1) {
                 T v = cv[a][r];
-                v.x -= re[a][r];
-                v.y -= im[a][r];
+                if (M3) {
+                    v.x -= re[a][r] - im[a][r];                          // P1 - P2
+                    v.y -= p3[a][r] - re[a][r] - im[a][r];               // P3 - P1 - P2
+                } else {
+                    v.x -= re[a][r];
+                    v.y -= im[a][r];
+                }
                 A[(size_t)c * N + irow] = v;
             }
         }
@@ -1397,7 +1427,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         const bool staged = h->lu_gemm_staged != 0;
         const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nf);
         if (staged || sizeof(T) != sizeof(cplx)) hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
-        else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+        else {
+            static const bool m3_off = getenv("FH_LU_3M") && atoi(getenv("FH_LU_3M")) == 0;
+            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+            else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+        }
         fh_prof_end(h);
     };
     // measured (cfg 2 / cfg 5): at N = 4096 a 256-wide outer block is neutral, at N = 8192 it saves 4-6 % (the k = 256
