@@ -252,208 +252,29 @@ extern "C" int feasthip_synchronize(feasthip_handle h) {
 // ---------------------------------------------------------------------------------------
 // problem definition
 // ---------------------------------------------------------------------------------------
-template <typename VT>
-struct host_csr {
-    std::vector<int64_t> ptr, idx;
-    std::vector<VT> val;
-};
-
-// Convert (CSR|CSC, base) input to 0-based CSR with sorted rows.
-template <typename VT>
-static bool to_csr0(int64_t N, int index_base, int storage, int64_t nnz, const int64_t* ptr, const int64_t* idx,
-                    const VT* val, host_csr<VT>& out) {
-    for (int64_t i = 0; i <= N; ++i)
-        if (ptr[i] - index_base < 0 || ptr[i] - index_base > nnz) return false;
-    for (int64_t k = 0; k < nnz; ++k)
-        if (idx[k] - index_base < 0 || idx[k] - index_base >= N) return false;
-    out.ptr.assign(N + 1, 0);
-    out.idx.resize(nnz);
-    out.val.resize(nnz);
-    if (storage == FEASTHIP_STORAGE_CSR) {
-        for (int64_t i = 0; i <= N; ++i) out.ptr[i] = ptr[i] - index_base;
-        for (int64_t k = 0; k < nnz; ++k) { out.idx[k] = idx[k] - index_base; out.val[k] = val[k]; }
-    } else {
-        // CSC -> CSR: counting transpose (entry (r, c) stored in column c)
-        for (int64_t k = 0; k < nnz; ++k) out.ptr[idx[k] - index_base + 1]++;
-        for (int64_t i = 0; i < N; ++i) out.ptr[i + 1] += out.ptr[i];
-        std::vector<int64_t> fill(out.ptr.begin(), out.ptr.end() - 1);
-        for (int64_t c = 0; c < N; ++c)
-            for (int64_t k = ptr[c] - index_base; k < ptr[c + 1] - index_base; ++k) {
-                int64_t r = idx[k] - index_base;
-                int64_t o = fill[r]++;
-                out.idx[o] = c;
-                out.val[o] = val[k];
-            }
-    }
-    // sort each row by column (insertion sort: rows are short / mostly sorted)
-    for (int64_t i = 0; i < N; ++i) {
-        int64_t a = out.ptr[i], b = out.ptr[i + 1];
-        bool sorted = true;
-        for (int64_t k = a + 1; k < b; ++k) if (out.idx[k] < out.idx[k - 1]) { sorted = false; break; }
-        if (sorted) continue;
-        std::vector<std::pair<int64_t, VT>> row;
-        row.reserve(b - a);
-        for (int64_t k = a; k < b; ++k) row.push_back({out.idx[k], out.val[k]});
-        std::stable_sort(row.begin(), row.end(), [](const std::pair<int64_t, VT>& x, const std::pair<int64_t, VT>& y) { return x.first < y.first; });
-        for (int64_t k = a; k < b; ++k) { out.idx[k] = row[k - a].first; out.val[k] = row[k - a].second; }
-    }
-    return true;
-}
-
-static inline double vzero(double) { return 0.0; }
-static inline cplx vzero(cplx) { return cmake(0, 0); }
-static inline double vadd(double a, double b) { return a + b; }
-static inline cplx vadd(cplx a, cplx b) { return cadd(a, b); }
-
-// ---------------------------------------------------------------------------------------
-// Row blocks for the LDS-window SpMM (fh_sparse.hip).  That kernel stages the X rows a block of at most FH_SPMM_R
-// consecutive matrix rows touches into LDS; it only pays when most of a block's column indices fall inside the block and
-// the rest hit few distinct rows.  Ingest therefore renumbers the unknowns by recursive bisection of the union pattern:
-// breadth-first levels from a pseudo-peripheral vertex of the part, cut at a multiple of FH_SPMM_R near the middle, both
-// halves again, until a part fits one block.  On the 7-point pattern of cfg 3 a 128-row block reaches 133 distinct
-// outside rows on average (greedy graph growing, tried first: 281).  The permutation never leaves the library: panels are
-// permuted when they cross the C ABI (column-major in caller order <-> row-major panel in block order), every reduction is
-// order independent, results are for the matrix as the caller defined it.  perm[new] = old; blk_start: first row of every
-// block (+ N).
-// ---------------------------------------------------------------------------------------
-static void fh_block_partition(int64_t N, const std::vector<int>& rowptr, const std::vector<int>& col, int R,
-                               std::vector<int>& perm, std::vector<int>& blk_start) {
-    perm.resize(N);
-    for (int64_t i = 0; i < N; ++i) perm[i] = (int)i;
-    blk_start.clear();
-    std::vector<int> part(N, 0), seen(N, -1), buf, probe;
-    buf.reserve(N);
-    int next_pid = 1, next_id = 0;
-    // breadth-first order of part `pid` from `start` (marks: seen[v] = id), appended to out; returns the last vertex reached
-    auto bfs = [&](int start, int pid, int id, std::vector<int>& out) -> int {
-        const size_t first = out.size();
-        seen[start] = id;
-        out.push_back(start);
-        for (size_t head = first; head < out.size(); ++head) {
-            const int v = out[head];
-            for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
-                const int u = col[k];
-                if (part[u] == pid && seen[u] != id) { seen[u] = id; out.push_back(u); }
-            }
-        }
-        return out.back();
-    };
-    struct range { int64_t lo, hi; int pid; };
-    std::vector<range> stack, leaves;
-    stack.push_back({0, N, 0});
-    while (!stack.empty()) {
-        const range r = stack.back();
-        stack.pop_back();
-        const int64_t n = r.hi - r.lo;
-        if (n <= R) { leaves.push_back(r); continue; }
-        // level order of the part: every connected component from a pseudo-peripheral vertex (the far end of a probe BFS)
-        const int id_probe = next_id++, id_order = next_id++;
-        buf.clear();
-        for (int64_t i = r.lo; i < r.hi; ++i) {
-            const int v = perm[i];
-            if (seen[v] == id_order) continue;                 // placed with an earlier component
-            probe.clear();
-            const int far = bfs(v, r.pid, id_probe, probe);
-            bfs(far, r.pid, id_order, buf);
-        }
-        for (int64_t i = 0; i < n; ++i) perm[r.lo + i] = buf[i];
-        int64_t left = ((n / 2 + R / 2) / R) * R;              // cut at a multiple of R near the middle: full blocks
-        left = std::max<int64_t>(R, std::min<int64_t>(left, n - 1));
-        const int p1 = next_pid++, p2 = next_pid++;
-        for (int64_t i = 0; i < left; ++i) part[perm[r.lo + i]] = p1;
-        for (int64_t i = left; i < n; ++i) part[perm[r.lo + i]] = p2;
-        stack.push_back({r.lo + left, r.hi, p2});
-        stack.push_back({r.lo, r.lo + left, p1});
-    }
-    std::sort(leaves.begin(), leaves.end(), [](const range& a, const range& b) { return a.lo < b.lo; });
-    for (const range& r : leaves) blk_start.push_back((int)r.lo);
-    blk_start.push_back((int)N);
-}
+static inline cplx fh_ing_zero(cplx) { return cmake(0, 0); }
+static inline cplx fh_ing_add(cplx a, cplx b) { return cadd(a, b); }
+#define FH_INGEST_STORAGE_CSR FEASTHIP_STORAGE_CSR
+#include "fh_ingest.hpp"       // host side of the ingest (pure C++; also compiled under ASan/UBSan by tests/host_ingest_harness.cpp)
 
 template <typename VT>
 static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage, int64_t nnzA, const int64_t* ptrA,
                          const int64_t* idxA, const VT* valA, int64_t nnzB, const int64_t* ptrB, const int64_t* idxB,
                          const VT* valB) {
-    host_csr<VT> A, B;
-    if (!to_csr0<VT>(N, index_base, storage, nnzA, ptrA, idxA, valA, A)) {
-        h->last_error = "feasthip_set_csr: malformed A (pointer/index out of range)";
-        return FEASTHIP_ERROR_N;
-    }
-    const bool hasB = ptrB != nullptr;
-    if (hasB && !to_csr0<VT>(N, index_base, storage, nnzB, ptrB, idxB, valB, B)) {
-        h->last_error = "feasthip_set_csr: malformed B (pointer/index out of range)";
-        return FEASTHIP_ERROR_N;
-    }
-    // union pattern, duplicates summed
-    std::vector<int> rowptr(N + 1, 0), col;
-    std::vector<VT> av, bv;
-    col.reserve(nnzA + (hasB ? nnzB : 0));
-    av.reserve(col.capacity());
-    if (hasB) bv.reserve(col.capacity());
-    for (int64_t i = 0; i < N; ++i) {
-        int64_t ka = A.ptr[i], ea = A.ptr[i + 1];
-        int64_t kb = hasB ? B.ptr[i] : 0, eb = hasB ? B.ptr[i + 1] : 0;
-        while (ka < ea || kb < eb) {
-            int64_t ca = ka < ea ? A.idx[ka] : INT64_MAX;
-            int64_t cb = kb < eb ? B.idx[kb] : INT64_MAX;
-            int64_t c = std::min(ca, cb);
-            VT a = vzero(VT()), b = vzero(VT());
-            while (ka < ea && A.idx[ka] == c) { a = vadd(a, A.val[ka]); ++ka; }
-            while (kb < eb && B.idx[kb] == c) { b = vadd(b, B.val[kb]); ++kb; }
-            col.push_back((int)c);
-            av.push_back(a);
-            if (hasB) bv.push_back(b);
-        }
-        if (col.size() > (size_t)INT32_MAX) { h->last_error = "feasthip_set_csr: nnz exceeds int32"; return FEASTHIP_ERROR_MEMORY; }
-        rowptr[i + 1] = (int)col.size();
-    }
-    int kl_ = 0, ku_ = 0;
-    for (int64_t i = 0; i < N; ++i)
-        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-            kl_ = std::max(kl_, (int)(i - col[k]));
-            ku_ = std::max(ku_, (int)(col[k] - i));
-        }
-    fh_free_problem(h);
-    h->csr_kl = kl_; h->csr_ku = ku_;
-    // Renumber into row blocks when the pattern is too wide for the banded LU anyway (that solver needs caller order)
-    std::vector<int> perm, blk_start;
-    // OFF by default: the LDS-window SpMM it feeds measured slower than the gather kernel on cfg 3 (57 vs 33 us per node,
-    // DESIGN.md section 5) -- FH_REORDER=1 renumbers wide-band matrices and switches that kernel on, FH_REORDER=2 does so
-    // whenever there are at least two blocks (test rigs push small problems through it)
+    // OFF by default: the LDS-window SpMM the renumbering feeds measured slower than the gather kernel on cfg 3 (57 vs 33 us
+    // per node) -- FH_REORDER=1 renumbers wide-band matrices and switches that kernel on, FH_REORDER=2
+    // does so whenever there are at least two blocks (test rigs push small problems through it)
     static const int reorder_mode = getenv("FH_REORDER") ? atoi(getenv("FH_REORDER")) : 0;
-    if ((reorder_mode == 1 && N >= 4 * FH_SPMM_R && kl_ + ku_ > 512) || (reorder_mode == 2 && N >= 2 * FH_SPMM_R)) {
-        fh_block_partition(N, rowptr, col, FH_SPMM_R, perm, blk_start);
-        std::vector<int> inv(N);
-        for (int64_t i = 0; i < N; ++i) inv[perm[i]] = (int)i;
-        std::vector<int> rp2(N + 1, 0), col2(col.size());
-        std::vector<VT> av2(av.size()), bv2(bv.size());
-        std::vector<std::pair<int, int>> row;
-        for (int64_t i = 0; i < N; ++i) {
-            const int o = perm[i];
-            row.clear();
-            for (int k = rowptr[o]; k < rowptr[o + 1]; ++k) row.push_back({inv[col[k]], k});
-            std::sort(row.begin(), row.end());
-            int w = rp2[i];
-            for (auto& e : row) {
-                col2[w] = e.first; av2[w] = av[e.second];
-                if (hasB) bv2[w] = bv[e.second];
-                ++w;
-            }
-            rp2[i + 1] = w;
-        }
-        rowptr.swap(rp2); col.swap(col2); av.swap(av2); bv.swap(bv2);
-    }
-    // The nonzero with the LARGEST column index goes first in its row.  k_spmm sweeps the rows in ascending order, so that
-    // is the X row nobody has touched yet (the one gather of a row that comes from HBM, not from L2): the kernel
-    // issues it one row step ahead (fh_sparse.hip).  The order inside a row means nothing else to any kernel.
-    for (int64_t i = 0; i < N; ++i) {
-        int kmax = rowptr[i];
-        for (int k = rowptr[i] + 1; k < rowptr[i + 1]; ++k) if (col[k] > col[kmax]) kmax = k;
-        if (kmax != rowptr[i]) {
-            std::swap(col[kmax], col[rowptr[i]]); std::swap(av[kmax], av[rowptr[i]]);
-            if (hasB) std::swap(bv[kmax], bv[rowptr[i]]);
-        }
-    }
+    fh_prepared<VT> P;
+    std::string err;
+    const int prc = fh_prepare_csr<VT>(N, index_base, storage, nnzA, ptrA, idxA, valA, nnzB, ptrB, idxB, valB, reorder_mode,
+                                       FH_SPMM_R, FH_SPMM_EXT, sizeof(VT) == sizeof(double), P, err);
+    if (prc) { h->last_error = "feasthip_set_csr: " + err; return prc == 3 ? FEASTHIP_ERROR_MEMORY : FEASTHIP_ERROR_N; }
+    const bool hasB = ptrB != nullptr;
+    fh_free_problem(h);
+    h->csr_kl = P.kl; h->csr_ku = P.ku;
+    const std::vector<int>& rowptr = P.rowptr;
+    const std::vector<int>& col = P.col;
     fh_csr& d = h->csr;
     d.N = N; d.nnz = (int64_t)col.size(); d.is_complex = sizeof(VT) == sizeof(cplx); d.b_identity = hasB ? 0 : 1;
     FH_CHECK(hipMalloc((void**)&d.rowptr, (N + 1) * sizeof(int)));
@@ -461,73 +282,38 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
     FH_CHECK(hipMalloc(&d.aval, std::max<size_t>(1, col.size()) * sizeof(VT)));
     FH_CHECK(hipMemcpy(d.rowptr, rowptr.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice));
     FH_CHECK(hipMemcpy(d.col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
-    FH_CHECK(hipMemcpy(d.aval, av.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
+    FH_CHECK(hipMemcpy(d.aval, P.av.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
     if (hasB) {
         FH_CHECK(hipMalloc(&d.bval, std::max<size_t>(1, col.size()) * sizeof(VT)));
-        FH_CHECK(hipMemcpy(d.bval, bv.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.bval, P.bv.data(), col.size() * sizeof(VT), hipMemcpyHostToDevice));
     }
-    if (sizeof(VT) == sizeof(double)) {
-        // chunk-of-8 copy of the rows for k_spmm_row (fh_sparse.hip): one s_load_dwordx8 / x16 per chunk, no tail tests
-        std::vector<int> rp8(N + 1, 0);
-        for (int64_t i = 0; i < N; ++i) rp8[i + 1] = rp8[i] + (rowptr[i + 1] - rowptr[i] + 7) / 8;
-        const size_t n8 = (size_t)rp8[N] * 8;
-        std::vector<int> col8(std::max<size_t>(8, n8));
-        std::vector<double> a8(std::max<size_t>(8, n8), 0.0), b8(hasB ? std::max<size_t>(8, n8) : 0, 0.0);
-        const double* avd = (const double*)av.data();
-        const double* bvd = (const double*)bv.data();
-        for (int64_t i = 0; i < N; ++i) {
-            size_t w = (size_t)rp8[i] * 8;
-            for (int k = rowptr[i]; k < rowptr[i + 1]; ++k, ++w) { col8[w] = col[k]; a8[w] = avd[k]; if (hasB) b8[w] = bvd[k]; }
-            for (; w < (size_t)rp8[i + 1] * 8; ++w) col8[w] = (int)i;
-        }
+    if (!P.rp8.empty()) {
         FH_CHECK(hipMalloc((void**)&d.rp8, (N + 1) * sizeof(int)));
-        FH_CHECK(hipMalloc((void**)&d.col8, col8.size() * sizeof(int)));
-        FH_CHECK(hipMalloc((void**)&d.a8, a8.size() * sizeof(double)));
-        FH_CHECK(hipMemcpy(d.rp8, rp8.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice));
-        FH_CHECK(hipMemcpy(d.col8, col8.data(), col8.size() * sizeof(int), hipMemcpyHostToDevice));
-        FH_CHECK(hipMemcpy(d.a8, a8.data(), a8.size() * sizeof(double), hipMemcpyHostToDevice));
+        FH_CHECK(hipMalloc((void**)&d.col8, P.col8.size() * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.a8, P.a8.size() * sizeof(double)));
+        FH_CHECK(hipMemcpy(d.rp8, P.rp8.data(), (N + 1) * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.col8, P.col8.data(), P.col8.size() * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.a8, P.a8.data(), P.a8.size() * sizeof(double), hipMemcpyHostToDevice));
         if (hasB) {
-            FH_CHECK(hipMalloc((void**)&d.b8, b8.size() * sizeof(double)));
-            FH_CHECK(hipMemcpy(d.b8, b8.data(), b8.size() * sizeof(double), hipMemcpyHostToDevice));
+            FH_CHECK(hipMalloc((void**)&d.b8, P.b8.size() * sizeof(double)));
+            FH_CHECK(hipMemcpy(d.b8, P.b8.data(), P.b8.size() * sizeof(double), hipMemcpyHostToDevice));
         }
     }
-    if (!perm.empty()) {
+    if (!P.perm.empty()) {
+        const int nb = (int)P.blk_start.size() - 1;
         FH_CHECK(hipMalloc((void**)&d.perm, N * sizeof(int)));
-        FH_CHECK(hipMemcpy(d.perm, perm.data(), N * sizeof(int), hipMemcpyHostToDevice));
-        // LDS slots of every nonzero
-        const int nb = (int)blk_start.size() - 1;
-        std::vector<int> ext_ptr(nb + 1, 0), ext_idx;
-        std::vector<unsigned short> lcol(col.size(), 0);
-        std::vector<int> uniq;
-        for (int b = 0; b < nb; ++b) {
-            const int r0 = blk_start[b], r1 = blk_start[b + 1];
-            uniq.clear();
-            for (int k = rowptr[r0]; k < rowptr[r1]; ++k) if (col[k] < r0 || col[k] >= r1) uniq.push_back(col[k]);
-            std::sort(uniq.begin(), uniq.end());
-            uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-            if ((int)uniq.size() > FH_SPMM_EXT) uniq.resize(FH_SPMM_EXT);       // the rest is gathered from global memory
-            for (int k = rowptr[r0]; k < rowptr[r1]; ++k) {
-                const int c = col[k];
-                if (c >= r0 && c < r1) lcol[k] = (unsigned short)(c - r0);
-                else {
-                    auto it = std::lower_bound(uniq.begin(), uniq.end(), c);
-                    lcol[k] = (it != uniq.end() && *it == c) ? (unsigned short)(FH_SPMM_R + (it - uniq.begin())) : (unsigned short)0xFFFF;
-                }
-            }
-            ext_idx.insert(ext_idx.end(), uniq.begin(), uniq.end());
-            ext_ptr[b + 1] = (int)ext_idx.size();
-        }
+        FH_CHECK(hipMemcpy(d.perm, P.perm.data(), N * sizeof(int), hipMemcpyHostToDevice));
         d.nblk = nb;
         FH_CHECK(hipMalloc((void**)&d.blk_start, (nb + 1) * sizeof(int)));
         FH_CHECK(hipMalloc((void**)&d.ext_ptr, (nb + 1) * sizeof(int)));
-        FH_CHECK(hipMalloc((void**)&d.ext_idx, std::max<size_t>(1, ext_idx.size()) * sizeof(int)));
-        FH_CHECK(hipMalloc((void**)&d.lcol, std::max<size_t>(1, lcol.size()) * sizeof(unsigned short)));
-        FH_CHECK(hipMemcpy(d.blk_start, blk_start.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
-        FH_CHECK(hipMemcpy(d.ext_ptr, ext_ptr.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
-        FH_CHECK(hipMemcpy(d.ext_idx, ext_idx.data(), ext_idx.size() * sizeof(int), hipMemcpyHostToDevice));
-        FH_CHECK(hipMemcpy(d.lcol, lcol.data(), lcol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+        FH_CHECK(hipMalloc((void**)&d.ext_idx, std::max<size_t>(1, P.ext_idx.size()) * sizeof(int)));
+        FH_CHECK(hipMalloc((void**)&d.lcol, std::max<size_t>(1, P.lcol.size()) * sizeof(unsigned short)));
+        FH_CHECK(hipMemcpy(d.blk_start, P.blk_start.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.ext_ptr, P.ext_ptr.data(), (nb + 1) * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.ext_idx, P.ext_idx.data(), P.ext_idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        FH_CHECK(hipMemcpy(d.lcol, P.lcol.data(), P.lcol.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
         if (getenv("FH_DEBUG_TIMING"))
-            fprintf(stderr, "[feasthip] renumbered into %d row blocks, %.1f outside rows per block on average\n", nb, nb ? (double)ext_idx.size() / nb : 0.0);
+            fprintf(stderr, "[feasthip] renumbered into %d row blocks, %.1f outside rows per block on average\n", nb, nb ? (double)P.ext_idx.size() / nb : 0.0);
     }
     h->kind = 2;
     return 0;

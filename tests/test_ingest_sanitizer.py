@@ -1,0 +1,25 @@
+"""CPU sanitizer build of the library's host-side ingest (sanitizers): the pure-C++ half of
+feasthip_set_csr lives in feastkit.jl_amd/csrc/fh_ingest.hpp, which tests/host_ingest_harness.cpp compiles with gcc under
+AddressSanitizer + UndefinedBehaviorSanitizer and fuzzes with random pencils in every input form the C ABI takes
+(CSR/CSC, 0/1-based, unsorted rows, duplicates, empty rows, renumbering on and off, malformed pointers).  GPU
+sanitizers are not available on this pool; the device side is covered by the parity tests."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_host_ingest_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "host_ingest_harness"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra",
+           os.path.join(ROOT, "tests", "host_ingest_harness.cpp"), "-o", str(exe)]
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert build.returncode == 0, build.stdout[-4000:]
+    for seed in ("20260515", "7"):
+        run = subprocess.run([str(exe), "400", seed], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+        assert run.returncode == 0 and run.stdout.strip().endswith("ok 400"), run.stdout[-4000:]
