@@ -386,16 +386,24 @@ __global__ __launch_bounds__(FH_ROW_THREADS, FH_ROW_WAVES) void k_spmm_row(fh_sp
         for (int i = row_lo + slot * WPB + wave; i < row_hi; i += band) {
             const int c0 = rp8[i], c1 = rp8[i + 1];
             double ux = 0.0, uy = 0.0, vx = 0.0, vy = 0.0;
-            CT xown = fh_czero<CT>();
-            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4 || a.dot_mode == 6) xown = (X + (size_t)i * LD)[lane];
+            // the row's own X value once; the diagonal entry and the padding slots of a chunk (column == own row) take
+            // it from the register instead of gathering the same 1-KB line again: 7 requests per row of the 7-point
+            // stencil instead of 10 -- the kernel is bound by the rate of exactly these requests.
+            // The test is wave-uniform (scalar compare and branch).
+            const CT xown = (X + (size_t)i * LD)[lane];
             for (int ch = c0; ch < c1; ++ch) {
                 const ciptr cc = col8 + (size_t)ch * 8;
                 const cdptr aa = a8 + (size_t)ch * 8;
                 CT xs[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const CT* __restrict__ rowp = X + (size_t)cc[q] * LD;        // uniform base: SALU
-                    xs[q] = rowp[lane];
+                    const int j = cc[q];
+                    if (j != i) {
+                        const CT* __restrict__ rowp = X + (size_t)j * LD;        // uniform base: SALU
+                        xs[q] = rowp[lane];
+                    } else {
+                        xs[q] = xown;
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
