@@ -261,10 +261,13 @@ template <typename VT>
 static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage, int64_t nnzA, const int64_t* ptrA,
                          const int64_t* idxA, const VT* valA, int64_t nnzB, const int64_t* ptrB, const int64_t* idxB,
                          const VT* valB) {
-    // OFF by default: the LDS-window SpMM the renumbering feeds measured slower than the gather kernel on cfg 3 (57 vs 33 us
-    // per node) -- FH_REORDER=1 renumbers wide-band matrices and switches that kernel on, FH_REORDER=2
-    // does so whenever there are at least two blocks (test rigs push small problems through it)
-    static const int reorder_mode = getenv("FH_REORDER") ? atoi(getenv("FH_REORDER")) : 0;
+    // Row-block renumbering (fh_ingest.hpp: recursive bisection into 128-row blocks).  ON by default for wide patterns since
+    // round 3: the row-per-wave SpMM is bound by the traffic that misses L2 (1-KB rows: the two far stencil planes of the
+    // caller's order do not fit 4 MiB), and compact blocks keep a slice's gathers local -- cfg 3: 37 -> 30 us per node and
+    // launch, 163 -> 159 ms per solve.  (k_spmm, with its 256-B tiles, never cared: round 2.)  FH_REORDER=0 keeps the caller's
+    // order, FH_REORDER=2 renumbers whenever there are at least two blocks (test rigs push small problems through it).  The
+    // LDS-window kernel the renumbering was built for stays opt-in (FH_LDS_SPMM=1): 57 vs 33 us per node on cfg 3.
+    static const int reorder_mode = getenv("FH_REORDER") ? atoi(getenv("FH_REORDER")) : 1;
     fh_prepared<VT> P;
     std::string err;
     const int prc = fh_prepare_csr<VT>(N, index_base, storage, nnzA, ptrA, idxA, valA, nnzB, ptrB, idxB, valB, reorder_mode,
@@ -461,7 +464,7 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.U = c.U; a.u_node_stride = c.u_stride; a.dot_mode = c.dot_mode;
         a.partial1 = c.partial1; a.partial2 = c.partial2; a.node_active = c.node_active;
         a.counters = h->profiling ? h->d_counters : nullptr; a.m = c.m; a.uniform_coef = c.uniform_coef; a.prec = c.prec;
-        static const bool no_lds = getenv("FH_NO_LDS_SPMM") != nullptr;
+        static const bool no_lds = !(getenv("FH_LDS_SPMM") && atoi(getenv("FH_LDS_SPMM")) != 0);      // opt-in
         // (the LDS-window kernel keeps its active-node list in a 64-entry LDS array: wider node batches -- trapezoid
         //  contours put no bound on fpm[2] -- take the gather kernel, which has no such limit)
         const bool lds_kernel = h->csr.lcol && c.prec == 64 && !no_lds && c.nodes <= 64 && c.dot_mode != 6;   // (fused-COCG dots: gather kernel only)
@@ -1147,7 +1150,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         if (h->kind == 2 && h->csr.perm) {
-            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER; mode 2 renumbers narrow bands too): unset FH_REORDER or pick a Krylov solver";
+            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER=2 renumbers narrow bands too): use FH_REORDER=0 or pick a Krylov solver";
             return FEASTHIP_ERROR_FPM;
         }
         int64_t nfact = 0;
@@ -2416,7 +2419,7 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         if (h->kind == 2 && h->csr.perm) {
-            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER; mode 2 renumbers narrow bands too): unset FH_REORDER or pick a Krylov solver";
+            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER=2 renumbers narrow bands too): use FH_REORDER=0 or pick a Krylov solver";
             return FEASTHIP_ERROR_FPM;
         }
         int64_t nfact = 0;

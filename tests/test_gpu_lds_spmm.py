@@ -1,6 +1,7 @@
-"""The opt-in LDS-window SpMM path (FH_REORDER: ingest renumbering into 128-row blocks + k_spmm_lds, fh_sparse.hip /
-fh_api.hip).  It is off by default -- it measured slower than the gather kernel on cfg 3 -- but it
-is the north_star's "CSR SpMV staging rows through LDS" and stays correct: a worker process with FH_REORDER=2 pushes
+"""The opt-in LDS-window SpMM path (ingest renumbering into 128-row blocks + k_spmm_lds, fh_sparse.hip / fh_api.hip;
+FH_LDS_SPMM=1).  The kernel is off by default -- it measured slower than the gather kernels on cfg 3
+-- but it is the north_star's "CSR SpMV staging rows through LDS" and stays correct; the renumbering itself is ON by
+default for wide patterns since round 3 (it feeds the row-per-wave kernel).  A worker process with FH_REORDER=2 pushes
 matrix products, Krylov solves, a contour sweep and a full FEAST solve through it and compares with numpy / the
 closed form.  The renumbering must be invisible: every result is for the matrix as the caller defined it."""
 import os
@@ -74,8 +75,9 @@ print("lds path ok")
 def test_lds_window_spmm_path(engine, tmp_path):
     script = tmp_path / "lds_worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, FH_REORDER="2", FH_DEBUG_TIMING="1")
-    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
-    out = p.stdout.decode()
-    assert p.returncode == 0 and "lds path ok" in out, out
-    assert "renumbered into" in out          # the path under test really ran
+    for lds in ("1", "0"):        # the LDS-window kernel, then the gather kernels on the same renumbered matrices
+        env = dict(os.environ, FH_REORDER="2", FH_LDS_SPMM=lds, FH_DEBUG_TIMING="1")
+        p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+        out = p.stdout.decode()
+        assert p.returncode == 0 and "lds path ok" in out, out
+        assert "renumbered into" in out          # the path under test really ran
