@@ -1997,29 +1997,41 @@ extern "C" int feasthip_project_dev(feasthip_handle h, int64_t r64, const void* 
     cplx *d1, *d0;
     if ((rc = fh_upload_coefs(h, "pj_one", one, &d1))) return rc;
     if ((rc = fh_upload_coefs(h, "pj_zero", zero, &d0))) return rc;
-    std::vector<cplx> Gh((size_t)ld * ld);
+    // both Gram matrices are queued before the ONE synchronisation that brings them to the host
+    if ((rc = fh_get_buf(h, "gram_G2", 2 * (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    G = (cplx*)p;
+    std::vector<cplx> Gh(2 * (size_t)ld * ld);
+    bool queued[2] = {false, false};
+    for (int which = 0; which < 2; ++which) {
+        cplx* out_host = (cplx*)(which == 0 ? Aq_host : Bq_host);
+        if (!out_host) continue;
+        if (which == 1 && fh_b_identity(h) && hermitize && !bilinear) continue;       // Aq_rank = I exactly, below
+        // (B = I without orthonormal Q, variant C: the operator kernel yields W = Q, so G = Q^H Q)
+        fh_op_call oc;
+        oc.m = r;
+        oc.X = Qp; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
+        oc.coefA = which == 0 ? d1 : d0; oc.coefB = which == 0 ? d0 : d1;
+        oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+        oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+        fh_apply_operator(h, ld, oc);
+        fh_prof_begin(h, "gram");
+        fh_launch_gram(Qp, W, N, ld, bilinear, gw, G + (size_t)which * ld * ld, h->stream);
+        fh_prof_end(h);
+        FH_CHECK(hipMemcpyAsync(Gh.data() + (size_t)which * ld * ld, G + (size_t)which * ld * ld, (size_t)ld * ld * sizeof(cplx),
+                                hipMemcpyDeviceToHost, h->stream));
+        queued[which] = true;
+    }
+    FH_CHECK(hipStreamSynchronize(h->stream));
     for (int which = 0; which < 2; ++which) {
         cplx* out_host = (cplx*)(which == 0 ? Aq_host : Bq_host);
         if (!out_host) continue;
         std::vector<cplx> res((size_t)r * r);
-        if (which == 1 && fh_b_identity(h) && hermitize && !bilinear) {
+        if (!queued[which]) {
             // variant A: Q is orthonormal, Aq_rank = I exactly (src/dense/feast_dense.jl:255-259)
             for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) res[(size_t)j * r + i] = cmake(i == j ? 1.0 : 0.0, 0.0);
         } else {
-            // (B = I without orthonormal Q, variant C: the operator kernel yields W = Q, so G = Q^H Q)
-            fh_op_call oc;
-            oc.m = r;
-            oc.X = Qp; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
-            oc.coefA = which == 0 ? d1 : d0; oc.coefB = which == 0 ? d0 : d1;
-            oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
-            oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
-            fh_apply_operator(h, ld, oc);
-            fh_prof_begin(h, "gram");
-            fh_launch_gram(Qp, W, N, ld, bilinear, gw, G, h->stream);
-            fh_prof_end(h);
-            FH_CHECK(hipMemcpyAsync(Gh.data(), G, Gh.size() * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
-            FH_CHECK(hipStreamSynchronize(h->stream));
-            for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) res[(size_t)j * r + i] = Gh[(size_t)j * ld + i];
+            const cplx* Gw = Gh.data() + (size_t)which * ld * ld;
+            for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) res[(size_t)j * r + i] = Gw[(size_t)j * ld + i];
             if (hermitize && !bilinear) fh_hermitize(res, r);
         }
         memcpy(out_host, res.data(), res.size() * sizeof(cplx));
@@ -2180,18 +2192,9 @@ extern "C" int feasthip_ritz_residual_dev(feasthip_handle h, int64_t r64, const 
     fh_prof_end(h);
     std::vector<cplx> dots(ld);
     if (normalize && M > 0) {
-        // normalise the first M columns (src/dense/feast_dense.jl:301-305)
+        // normalise the first M columns (src/dense/feast_dense.jl:301-305): norms and scaling stay on the device
         fh_launch_dot_cols(Xp, Xp, N, ld, part, ddots, h->stream);
-        FH_CHECK(hipMemcpyAsync(dots.data(), ddots, ld * sizeof(cplx), hipMemcpyDeviceToHost, h->stream));
-        FH_CHECK(hipStreamSynchronize(h->stream));
-        std::vector<cplx> sc(ld, cmake(1, 0));
-        for (int c = 0; c < (int)M; ++c) {
-            double n = std::sqrt(dots[c].x);
-            if (n > 0) sc[c] = cmake(1.0 / n, 0);
-        }
-        cplx* dsc;
-        if ((rc = fh_upload_coefs(h, "rz_scale", sc, &dsc))) return rc;
-        fh_launch_scale_cols(Xp, dsc, N, ld, h->stream);
+        fh_launch_normalize_cols(Xp, ddots, N, ld, (int)M, h->stream);
     }
     fh_launch_from_panel(Xp, ld, N, r, (cplx*)dX, N, h->stream, fh_perm(h));
     if (M > 0 && res_host) {

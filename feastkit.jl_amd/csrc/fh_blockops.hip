@@ -165,6 +165,23 @@ void fh_launch_scale_cols(cplx* X, const cplx* s, int N, int ld, hipStream_t st)
     hipLaunchKernelGGL(k_scale_cols, dim3(fh_vec_nblk(N, ld)), dim3(FH_BLOCK), 0, st, X, s, (size_t)N * ld, ld);
 }
 
+// X[:, c] /= sqrt(dots[c].x) for c < M (columns with a zero norm and columns >= M are left alone): the normalisation of the
+// Ritz vectors without a host round trip for the norms
+__global__ __launch_bounds__(FH_BLOCK) void k_normalize_cols(cplx* __restrict__ X, const cplx* __restrict__ dots,
+                                                              size_t total, int ld, int M) {
+    const int c = threadIdx.x % ld;
+    const double n2 = dots[c].x;
+    if (c >= M || !(n2 > 0.0)) return;
+    const double f = 1.0 / sqrt(n2);
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        cplx v = X[e];
+        X[e] = cmake(v.x * f, v.y * f);
+    }
+}
+void fh_launch_normalize_cols(cplx* X, const cplx* dots, int N, int ld, int M, hipStream_t st) {
+    hipLaunchKernelGGL(k_normalize_cols, dim3(fh_vec_nblk(N, ld)), dim3(FH_BLOCK), 0, st, X, dots, (size_t)N * ld, ld, M);
+}
+
 __global__ __launch_bounds__(FH_BLOCK) void k_gather_cols(const cplx* __restrict__ src, const int* __restrict__ perm,
                                                            int count, size_t total, int ld, cplx* __restrict__ dst) {
     const int c = threadIdx.x % ld;

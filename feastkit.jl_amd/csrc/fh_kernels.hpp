@@ -147,6 +147,8 @@ int fh_kry_nblk(int N, int ld, int nodes);
 void fh_launch_dot_cols(const cplx* U, const cplx* V, int N, int ld, cplx* work, cplx* out, hipStream_t st);
 // X[:,c] *= s[c]
 void fh_launch_scale_cols(cplx* X, const cplx* s, int N, int ld, hipStream_t st);
+// X[:, c] /= sqrt(dots[c].x) for c < M, on the device (dots: per-column <x, x> from fh_launch_dot_cols)
+void fh_launch_normalize_cols(cplx* X, const cplx* dots, int N, int ld, int M, hipStream_t st);
 // Xout = Q * V   (V: ld x ld column-major on device, zero padded)
 void fh_launch_small_matmul(const cplx* Q, const cplx* V, int N, int ld, cplx* Xout, hipStream_t st);
 // dst[:,k] = src[:,perm[k]] for k < count else 0

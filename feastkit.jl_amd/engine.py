@@ -44,7 +44,8 @@ class HipEngine:
         if rc != 0 or not h:
             raise FeastHipUnavailable(f"feasthip_create(device={device_index}) failed with code {rc}")
         self.h = h
-        self._chk(self.lib.feasthip_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._stream_handle = torch.cuda.current_stream(self.device).cuda_stream
+        self._chk(self.lib.feasthip_set_stream(self.h, C.c_void_p(self._stream_handle)))
         self.N = 0
         self.b_identity = True
         self.last_stats = {}
@@ -276,7 +277,9 @@ class HipEngine:
         first; every C-ABI call returns synchronised, which orders torch behind the library."""
         cur = self.torch.cuda.current_stream(self.device)
         cur.synchronize()
-        self._chk(self.lib.feasthip_set_stream(self.h, C.c_void_p(cur.cuda_stream)))
+        if cur.cuda_stream != getattr(self, "_stream_handle", None):      # (set_stream drains the library's stream: only on a change)
+            self._chk(self.lib.feasthip_set_stream(self.h, C.c_void_p(cur.cuda_stream)))
+            self._stream_handle = cur.cuda_stream
 
     # -- hot path -------------------------------------------------------------------
     def contour_apply(self, dQ, m, ritz_lambda=None, want_moments=False):
