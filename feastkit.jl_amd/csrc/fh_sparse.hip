@@ -200,8 +200,7 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 if (!BIDENT) nb = bval[k0n + l16];
             }
             CT acc = fh_czero<CT>();
-            CT xown = fh_czero<CT>();
-            if (BIDENT || a.dot_mode == 2 || a.dot_mode == 4 || a.dot_mode == 6) xown = X[(size_t)i * LD + c];
+            const CT xown = X[(size_t)i * LD + c];
             if (BIDENT) acc = cmul(cb, xown);            // B = I contributes cb * x_i
             for (int kb = k0; kb < k1; kb += 16) {
                 if (kb != k0) {                          // rows longer than 16 nonzeros: load on demand
@@ -232,7 +231,11 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                             if (head) { xs[0] = xfar_cur; continue; }
                         }
                         const int j = fh_bc16(mycol, q0 + q);
-                        xs[q] = X[(size_t)j * LD + c];
+                        // the diagonal entry and the slots past the row end point at the row itself: its value is in a
+                        // register already (xown) -- no second and third request for the same line (the kernel is bound
+                        // by its requests: 7 per stencil row instead of 10)
+                        xs[q] = xown;
+                        if (j != i) xs[q] = X[(size_t)j * LD + c];
                     }
                     if (head) {
                         // next row's far gather: the youngest load of this step
