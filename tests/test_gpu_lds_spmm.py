@@ -81,3 +81,18 @@ def test_lds_window_spmm_path(engine, tmp_path):
         out = p.stdout.decode()
         assert p.returncode == 0 and "lds path ok" in out, out
         assert "renumbered into" in out          # the path under test really ran
+
+
+@pytest.mark.parametrize("env", [{"FH_REORDER": "0"}, {"FH_COCG_FUSED": "0"}, {"FH_SPMM_ROW": "0"},
+                                 {"FH_REORDER": "0", "FH_COCG_FUSED": "0", "FH_SPMM_ROW": "0"}, {"FH_LU_3M": "0"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_comparison_switches_stay_correct(engine, tmp_path, env):
+    """The environment switches that select the round-2 forms (caller's row order, five-launch COCG iteration,
+    4-rows-per-wave SpMM, four-product LU update) exist so that every comparison quoted in DESIGN.md can be re-run on one
+    build: the same worker (products, Krylov solves against dense LAPACK, a contour sweep, a full FEAST solve) must pass
+    under each of them."""
+    script = tmp_path / "switch_worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    p = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **env), timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "lds path ok" in out, out
