@@ -48,6 +48,28 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30, dense_limit=12288)
     return "krylov"
 
 
+def _single_precision(*mats):
+    """True when every matrix given is float32 / complex64: the reference preserves the element type of such input
+    (test/runtests.jl:281-304) and stops at max(10^-fpm[3], sqrt(eps(Float32))) (src/core/feast_parameters.jl:398-405)."""
+    dts = [np.dtype((M.dtype if not sp.issparse(M) else M.data.dtype)) for M in mats if M is not None]
+    return bool(dts) and all(dt in (np.dtype(np.float32), np.dtype(np.complex64)) for dt in dts)
+
+
+def _promote(M):
+    """float32 / complex64 -> float64 / complex128 (the C ABI takes f64 / c128 only: the shim converts on the way in and
+    casts the results back, so that single-precision callers keep their element types)."""
+    if M is None:
+        return None
+    dt = np.complex128 if np.iscomplexobj(M.data if sp.issparse(M) else M) else np.float64
+    return M.astype(dt)
+
+
+def _demote(res, cplx_lambda):
+    return FeastResult(res.lambda_.astype(np.complex64 if cplx_lambda else np.float32),
+                       res.q.astype(np.complex64 if np.iscomplexobj(res.q) else np.float32), res.M, res.res.astype(np.float32), res.info,
+                       float(res.epsout), res.loop, res.stats)
+
+
 def _densify(M):
     return None if M is None else np.asfortranarray(M.toarray())
 
@@ -109,6 +131,9 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
             raise ValueError("Matrix A must be Hermitian")
         if B is not None and not _is_hermitian(B):
             raise ValueError("Matrix B must be Hermitian positive definite")
+    single = _single_precision(A, B)
+    if single:
+        A, B = _promote(A), _promote(B)
     Emin, Emax = float(interval[0]), float(interval[1])
     fpm = feastinit() if fpm is None else fpm
     aspect_unset = int(fpm[18]) == FEAST_UNINITIALIZED      # the caller left the contour shape to the library
@@ -157,11 +182,13 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,
                               inner_precision=inner_precision, group=group, Q0=Q0, contour=contour,
-                              contour_policy=contour_policy)
+                              contour_policy=contour_policy, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
     if real_input:
         res = FeastResult(res.lambda_, np.real(res.q), res.M, res.res, res.info, res.epsout, res.loop, res.stats)
+    if single:
+        res = _demote(res, cplx_lambda=False)
     return res
 
 
@@ -175,6 +202,9 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
         raise ValueError("Matrix A must be square")
     if not radius > 0:
         raise ValueError("radius must be positive")
+    single = _single_precision(A, B)
+    if single:
+        A, B = _promote(A), _promote(B)
     fpm = feastinit() if fpm is None else fpm
     feastdefault(fpm)
     M0 = min(int(M0), A.shape[0])
@@ -197,7 +227,10 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
     eng = _engine(engine, device)
     res = feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver, inner_precision=inner_precision,
                              solver_tol=solver_tol, solver_maxiter=solver_maxiter,
-                             solver_restart=solver_restart, group=group, Q0=Q0, contour=contour)
+                             solver_restart=solver_restart, group=group, Q0=Q0, contour=contour,
+                             eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
+    if single:
+        res = _demote(res, cplx_lambda=True)
     return res

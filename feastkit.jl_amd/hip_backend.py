@@ -160,7 +160,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
                         preloaded=False, node_assignment="block", inner_precision=64, column_groups=1,
-                        spurious_filter=True, contour_policy=None):
+                        spurious_filter=True, contour_policy=None, eps_floor=0.0):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -313,7 +313,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
         dQ = engine.upload(Q_host)
     maxloop = int(fpm[4])
-    eps_tol = feast_tolerance(fpm)
+    eps_tol = max(feast_tolerance(fpm), float(eps_floor))      # eps_floor: sqrt(eps(Float32)) for single-precision callers
     epsout, info, loop_count, M_found, active = math.inf, 0, 0, 0, M0
     lam_vec = np.zeros(M0)
     res_vec = np.zeros(M0)
@@ -540,7 +540,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
 
 
 def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
-                      solver_restart=30, group=None, Q0=None, seed=20260515, inner_precision=64, contour=None):
+                      solver_restart=30, group=None, Q0=None, seed=20260515, inner_precision=64, contour=None, eps_floor=0.0):
     """Variant C (general, full contour, no factor 2, no orthonormalisation, residual
     without B): src/kernel/feast_kernel.jl:752-950 driven as in src/dense/feast_dense.jl:468-584."""
     N = A.shape[0]
@@ -569,7 +569,7 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
                       restart=solver_restart, cache_factors=True, factor_precision=32 if inner_precision == 32 else 64)
     Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
     dQ = engine.upload(Q_host)
-    eps_tol = feast_tolerance(fpm)
+    eps_tol = max(feast_tolerance(fpm), float(eps_floor))
     maxloop = int(fpm[4])
     loop = 0
     stats = {"krylov_iterations": 0, "factorizations": 0, "solve_seconds": 0.0}

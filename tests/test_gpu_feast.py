@@ -592,3 +592,30 @@ def test_wide_general_dense(engine):
     assert r.info == 0 and r.M == len(inside) == 70
     key = lambda x: (round(x.real, 6), round(x.imag, 6))
     assert np.allclose(sorted(r.lambda_, key=key), sorted(inside, key=key), atol=1e-8)
+
+
+def test_single_precision_element_types_preserved(engine):
+    """test/runtests.jl:281-304: Float32 / ComplexF32 input runs and keeps its element type in lambda and q (the :hip shim
+    promotes on the way in -- the C ABI is f64 / c128 -- and stops at max(10^-fpm[3], sqrt(eps(Float32))) like
+    src/core/feast_parameters.jl:398-405)."""
+    n = 4
+    A = (np.diag(np.full(n, 2.0)) - np.diag(np.ones(n - 1), 1) - np.diag(np.ones(n - 1), -1)).astype(np.float32)
+    B = np.eye(n, dtype=np.float32)
+    r = fk.feast(A, B, (np.float32(0.0), np.float32(4.0)), M0=n, engine=engine)
+    assert r.info == 0 and r.M >= 1 and r.lambda_.dtype == np.float32 and r.q.dtype == np.float32 and r.res.dtype == np.float32
+    want = 2.0 - 2.0 * np.cos(np.arange(1, n + 1) * np.pi / (n + 1))
+    assert r.M == n and np.abs(np.sort(r.lambda_) - want).max() < 1e-5
+    Ac = np.diag(np.array([0.25, 1.25, 2.25, 3.25], dtype=np.complex64))
+    rc = fk.feast(Ac, None, (-2.0, 2.0), M0=n, engine=engine)
+    assert rc.info == 0 and rc.M == 2 and rc.q.dtype == np.complex64 and rc.lambda_.dtype == np.float32
+    assert np.abs(np.sort(rc.lambda_) - [0.25, 1.25]).max() < 1e-5
+    As = sp.csr_matrix(A)
+    rs = fk.feast(As, None, (np.float32(0.0), np.float32(4.0)), M0=n, engine=engine)
+    assert rs.info == 0 and rs.M == n and rs.lambda_.dtype == np.float32 and rs.q.dtype == np.float32
+    G = np.array([[1, 2 + 1j], [0, 3]], dtype=np.complex64)
+    rg = fk.feast_general(G, None, 2.0, 2.5, M0=2, engine=engine)
+    assert rg.info == 0 and rg.M == 2 and rg.lambda_.dtype == np.complex64 and rg.q.dtype == np.complex64
+    assert np.abs(np.sort(rg.lambda_.real) - [1.0, 3.0]).max() < 1e-5
+    # double-precision input is untouched
+    rd = fk.feast(A.astype(np.float64), None, (0.0, 4.0), M0=n, engine=engine)
+    assert rd.lambda_.dtype == np.float64 and rd.q.dtype == np.float64 and rd.epsout <= 1e-12
