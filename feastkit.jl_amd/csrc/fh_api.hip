@@ -276,6 +276,7 @@ static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage
     const bool hasB = ptrB != nullptr;
     fh_free_problem(h);
     h->csr_kl = P.kl; h->csr_ku = P.ku;
+    h->host_rowptr = P.rowptr; h->host_col = P.col;
     const std::vector<int>& rowptr = P.rowptr;
     const std::vector<int>& col = P.col;
     fh_csr& d = h->csr;
@@ -335,6 +336,13 @@ extern "C" int feasthip_set_csr(feasthip_handle h, int64_t N, int is_complex, in
     if (is_complex)
         return set_csr_typed<cplx>(h, N, index_base, storage, nnzA, ptrA, idxA, (const cplx*)valA, nnzB, ptrB, idxB, (const cplx*)valB);
     return set_csr_typed<double>(h, N, index_base, storage, nnzA, ptrA, idxA, (const double*)valA, nnzB, ptrB, idxB, (const double*)valB);
+}
+
+extern "C" int feasthip_band_plan(feasthip_handle h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    return fh_banded_plan(h, kl, ku, bytes_per_node, blocked);
 }
 
 extern "C" int feasthip_set_dense(feasthip_handle h, int64_t N, int is_complex, const void* A, int64_t lda,
@@ -1149,10 +1157,6 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         if (rc) return rc;
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
-        if (h->kind == 2 && h->csr.perm) {
-            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER=2 renumbers narrow bands too): use FH_REORDER=0 or pick a Krylov solver";
-            return FEASTHIP_ERROR_FPM;
-        }
         int64_t nfact = 0;
         rc = fh_banded_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
         if (rc) return rc;
@@ -2421,10 +2425,6 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         if (rc) return rc;
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
-        if (h->kind == 2 && h->csr.perm) {
-            h->last_error = "banded LU needs the matrix in the caller's order, but it was renumbered into row blocks at ingest (FH_REORDER=2 renumbers narrow bands too): use FH_REORDER=0 or pick a Krylov solver";
-            return FEASTHIP_ERROR_FPM;
-        }
         int64_t nfact = 0;
         rc = fh_banded_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;

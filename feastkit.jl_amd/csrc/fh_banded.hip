@@ -12,6 +12,12 @@
 #include <vector>
 
 #include "fh_banded.hpp"
+#include "fh_dense.hpp"
+#include <string>
+static inline cplx fh_ing_zero(cplx) { return cmake(0, 0); }
+static inline cplx fh_ing_add(cplx a, cplx b) { return cadd(a, b); }
+#define FH_INGEST_STORAGE_CSR 0
+#include "fh_ingest.hpp"       // fh_rcm, fh_bandwidth
 #include "../../include/feasthip.h"
 
 #define FH_BLOCK 256
@@ -161,32 +167,118 @@ __global__ __launch_bounds__(FH_BLOCK) void k_band_solve(cplx* const* ABs, int* 
 
 // ---------------------------------------------------------------------------------------
 // host orchestration
+//
+// Band plan (made once per matrix, on first use).  The pattern is measured in the order it is stored on the device (the
+// ingest may have renumbered it).  A band of at most FH_BAND_NARROW (512) in that order goes to the one-workgroup
+// elimination above.  Anything wider is renumbered by reverse Cuthill-McKee (fh_ingest.hpp) if that narrows it and goes to
+// the blocked band LU on the dense kernels (fh_dense.hip, fh_wband_*): the sparse direct solver for general patterns.
+// FH_WBAND=1 sends every matrix there (tests).
 // ---------------------------------------------------------------------------------------
+#define FH_BAND_NARROW 512
+
 void fh_banded_free(feasthip_ctx* h) {
     for (void* p : h->band_factors) if (p) hipFree(p);
     for (int* p : h->band_pivots) if (p) hipFree(p);
     h->band_factors.clear(); h->band_pivots.clear(); h->band_valid.clear(); h->band_z.clear();
+    if (h->band_perm) hipFree(h->band_perm);
+    if (h->band_iperm) hipFree(h->band_iperm);
+    h->band_perm = nullptr; h->band_iperm = nullptr;
+    h->band_plan = 0; h->band_kl = 0; h->band_ku = 0;
+}
+
+static int band_make_plan(feasthip_ctx* h) {
+    if (h->band_plan) return 0;
+    if (h->kind != 2) { h->last_error = "banded LU needs a CSR matrix (feasthip_set_csr)"; return FEASTHIP_ERROR_FPM; }
+    const int64_t N = h->csr.N;
+    if ((int64_t)h->host_rowptr.size() != N + 1) { h->last_error = "banded LU: no host pattern"; return FEASTHIP_ERROR_INTERNAL; }
+    int kl0 = 0, ku0 = 0;
+    fh_bandwidth(N, h->host_rowptr, h->host_col, nullptr, kl0, ku0);
+    const bool force_wide = getenv("FH_WBAND") && atoi(getenv("FH_WBAND")) != 0;     // read per plan: tests switch it
+    if (!force_wide && kl0 + ku0 <= FH_BAND_NARROW) {
+        h->band_plan = 1; h->band_kl = kl0; h->band_ku = ku0;
+        return 0;
+    }
+    std::vector<int> perm, iperm(N);
+    fh_rcm(N, h->host_rowptr, h->host_col, perm);
+    for (int64_t i = 0; i < N; ++i) iperm[perm[i]] = (int)i;
+    int kl1 = 0, ku1 = 0;
+    fh_bandwidth(N, h->host_rowptr, h->host_col, iperm.data(), kl1, ku1);
+    // the elimination costs N kl (kl + ku): compare that, not the plain width
+    if ((double)kl1 * (kl1 + ku1) >= (double)kl0 * (kl0 + ku0)) {
+        for (int64_t i = 0; i < N; ++i) { perm[i] = (int)i; iperm[i] = (int)i; }
+        kl1 = kl0; ku1 = ku0;
+    }
+    FH_CHECK(hipMalloc((void**)&h->band_perm, N * sizeof(int)));
+    FH_CHECK(hipMalloc((void**)&h->band_iperm, N * sizeof(int)));
+    FH_CHECK(hipMemcpy(h->band_perm, perm.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    FH_CHECK(hipMemcpy(h->band_iperm, iperm.data(), N * sizeof(int), hipMemcpyHostToDevice));
+    h->band_plan = 2; h->band_kl = kl1; h->band_ku = ku1;
+    if (getenv("FH_DEBUG_TIMING"))
+        fprintf(stderr, "[feasthip] band plan: stored order kl %d ku %d, band order kl %d ku %d, %.2f GB per node\n", kl0, ku0, kl1, ku1,
+                (double)fh_wband_elems((int)N, kl1, ku1) * sizeof(cplx) / 1e9);
+    return 0;
+}
+
+static size_t band_slot_bytes(feasthip_ctx* h) {
+    const size_t N = (size_t)h->csr.N;
+    if (h->band_plan == 2) return fh_wband_elems((int)N, h->band_kl, h->band_ku) * sizeof(cplx);
+    return ((size_t)2 * h->band_kl + h->band_ku + 1) * N * sizeof(cplx);
 }
 
 static int band_check(feasthip_ctx* h) {
-    if (h->kind != 2) { h->last_error = "banded LU needs a CSR matrix (feasthip_set_csr)"; return FEASTHIP_ERROR_FPM; }
-    const int kl = h->csr_kl, ku = h->csr_ku;
-    const size_t lds = (size_t)(kl + kl + ku + 1) * sizeof(cplx);
-    if (lds > 60000) {
-        h->last_error = "banded LU: bandwidth too large (kl + (kl+ku) > ~3700); use an iterative solver";
+    int rc = band_make_plan(h);
+    if (rc) return rc;
+    if (h->band_plan == 1) {
+        const size_t lds = (size_t)(2 * h->band_kl + h->band_ku + 1) * sizeof(cplx);
+        if (lds > 60000) { h->last_error = "banded LU: internal (narrow plan with a wide band)"; return FEASTHIP_ERROR_INTERNAL; }
+    } else if (h->band_kl > 12000) {
+        h->last_error = "banded LU: band too wide after reordering (kl > 12000); use an iterative solver";
         return FEASTHIP_ERROR_FPM;
     }
     return 0;
 }
 
 static int band_ensure_slots(feasthip_ctx* h, int nslots) {
-    const size_t N = (size_t)h->csr.N, ldab = (size_t)2 * h->csr_kl + h->csr_ku + 1;
+    const size_t N = (size_t)h->csr.N;
+    const size_t bytes = band_slot_bytes(h);
+    const int missing = nslots - (int)h->band_factors.size();
+    if (missing > 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)missing * (double)bytes > 0.92 * (double)free_b) {
+            h->last_error = "banded LU: " + std::to_string(missing) + " factors of " + std::to_string(bytes >> 20) + " MiB do not fit the free device memory (" +
+                            std::to_string(free_b >> 20) + " MiB)";
+            return FEASTHIP_ERROR_MEMORY;
+        }
+    }
     while ((int)h->band_factors.size() < nslots) {
         void* f = nullptr; int* pv = nullptr;
-        if (hipMalloc(&f, ldab * N * sizeof(cplx)) != hipSuccess) { h->last_error = "hipMalloc(band factor)"; return FEASTHIP_ERROR_MEMORY; }
-        if (hipMalloc((void**)&pv, N * sizeof(int)) != hipSuccess) { hipFree(f); h->last_error = "hipMalloc(band pivots)"; return FEASTHIP_ERROR_MEMORY; }
+        if (hipMalloc(&f, bytes) != hipSuccess) { (void)hipGetLastError(); h->last_error = "hipMalloc(band factor)"; return FEASTHIP_ERROR_MEMORY; }
+        if (hipMalloc((void**)&pv, N * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); hipFree(f); h->last_error = "hipMalloc(band pivots)"; return FEASTHIP_ERROR_MEMORY; }
         h->band_factors.push_back(f); h->band_pivots.push_back(pv); h->band_valid.push_back(0); h->band_z.push_back(cmake(0, 0));
     }
+    return 0;
+}
+
+// device arrays of per-node pointers for the slots in `which`: storage (narrow) or matrix base (wide), pivots, (wide) perm
+static int band_pointer_arrays(feasthip_ctx* h, const std::vector<int>& which, cplx*** dabs_out, int*** dpvs_out, int*** dperms_out) {
+    const int nf = (int)which.size();
+    const size_t off = h->band_plan == 2 ? fh_wband_base_offset((int)h->csr.N, h->band_kl, h->band_ku) : 0;
+    void* p;
+    int rc;
+    std::vector<cplx*> abs(nf);
+    std::vector<int*> pvs(nf), perms(nf, h->band_perm);
+    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)h->band_factors[which[q]] + off; pvs[q] = h->band_pivots[which[q]]; }
+    if ((rc = fh_get_buf(h, "bd_ptrs", nf * sizeof(cplx*), &p))) return rc;
+    cplx** dabs = (cplx**)p;
+    if ((rc = fh_get_buf(h, "bd_pptrs", nf * sizeof(int*), &p))) return rc;
+    int** dpvs = (int**)p;
+    if ((rc = fh_get_buf(h, "bd_permptrs", nf * sizeof(int*), &p))) return rc;
+    int** dperms = (int**)p;
+    FH_CHECK(hipMemcpyAsync(dabs, abs.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(dperms, perms.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));      // the host vectors go out of scope
+    *dabs_out = dabs; *dpvs_out = dpvs; *dperms_out = dperms;
     return 0;
 }
 
@@ -194,72 +286,69 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
     const int nf = (int)which.size();
     info_out.assign(nf, 0);
     if (nf == 0) return 0;
-    const int N = (int)h->csr.N, kl = h->csr_kl, ku = h->csr_ku;
-    const size_t ldab = (size_t)2 * kl + ku + 1;
+    const int N = (int)h->csr.N, kl = h->band_kl, ku = h->band_ku;
     void* p;
     int rc;
-    std::vector<cplx*> abs(nf);
-    std::vector<int*> pvs(nf);
-    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)h->band_factors[which[q]]; pvs[q] = h->band_pivots[which[q]]; }
-    if ((rc = fh_get_buf(h, "bd_ptrs", nf * sizeof(cplx*), &p))) return rc;
-    cplx** dabs = (cplx**)p;
-    if ((rc = fh_get_buf(h, "bd_pptrs", nf * sizeof(int*), &p))) return rc;
-    int** dpvs = (int**)p;
+    cplx** dabs; int** dpvs; int** dperms;
+    if ((rc = band_pointer_arrays(h, which, &dabs, &dpvs, &dperms))) return rc;
     if ((rc = fh_get_buf(h, "bd_z", nf * sizeof(cplx), &p))) return rc;
     cplx* dz = (cplx*)p;
     if ((rc = fh_get_buf(h, "bd_info", nf * sizeof(int), &p))) return rc;
     int* dinfo = (int*)p;
-    FH_CHECK(hipMemcpyAsync(dabs, abs.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
-    FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemsetAsync(dinfo, 0, nf * sizeof(int), h->stream));
-    for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(abs[q], 0, ldab * N * sizeof(cplx), h->stream));
-    FH_CHECK(hipStreamSynchronize(h->stream));
-    const dim3 grid((N + FH_BLOCK - 1) / FH_BLOCK, nf), block(FH_BLOCK);
-    const bool bid = h->csr.b_identity != 0;
-    fh_prof_begin(h, "band_form");
-    if (h->csr.is_complex) {
-        if (bid) hipLaunchKernelGGL((k_band_form<cplx, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)nullptr, dabs, dz, N, kl, ku);
-        else hipLaunchKernelGGL((k_band_form<cplx, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dabs, dz, N, kl, ku);
+    if (h->band_plan == 2) {
+        std::vector<cplx*> abs(nf);
+        for (int q = 0; q < nf; ++q) abs[q] = (cplx*)h->band_factors[which[q]];
+        if ((rc = fh_wband_factor(h, nf, abs.data(), dabs, dpvs, dz, dinfo, h->band_iperm, kl, ku))) return rc;
     } else {
-        if (bid) hipLaunchKernelGGL((k_band_form<double, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)nullptr, dabs, dz, N, kl, ku);
-        else hipLaunchKernelGGL((k_band_form<double, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)h->csr.bval, dabs, dz, N, kl, ku);
+        const size_t ldab = (size_t)2 * kl + ku + 1;
+        for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(h->band_factors[which[q]], 0, ldab * N * sizeof(cplx), h->stream));
+        const dim3 grid((N + FH_BLOCK - 1) / FH_BLOCK, nf), block(FH_BLOCK);
+        const bool bid = h->csr.b_identity != 0;
+        fh_prof_begin(h, "band_form");
+        if (h->csr.is_complex) {
+            if (bid) hipLaunchKernelGGL((k_band_form<cplx, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)nullptr, dabs, dz, N, kl, ku);
+            else hipLaunchKernelGGL((k_band_form<cplx, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dabs, dz, N, kl, ku);
+        } else {
+            if (bid) hipLaunchKernelGGL((k_band_form<double, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)nullptr, dabs, dz, N, kl, ku);
+            else hipLaunchKernelGGL((k_band_form<double, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)h->csr.bval, dabs, dz, N, kl, ku);
+        }
+        fh_prof_end(h);
+        fh_prof_begin(h, "band_lu");
+        hipLaunchKernelGGL(k_band_lu, dim3(nf), dim3(BAND_THREADS), (size_t)(kl + kl + ku + 1) * sizeof(cplx), h->stream, dabs, dpvs, N, kl, ku, dinfo);
+        fh_prof_end(h);
     }
-    fh_prof_end(h);
-    fh_prof_begin(h, "band_lu");
-    hipLaunchKernelGGL(k_band_lu, dim3(nf), dim3(BAND_THREADS), (size_t)(kl + kl + ku + 1) * sizeof(cplx), h->stream, dabs, dpvs, N, kl, ku, dinfo);
-    fh_prof_end(h);
     FH_CHECK(hipMemcpyAsync(info_out.data(), dinfo, nf * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
     return 0;
 }
 
-static int band_solve_batch(feasthip_ctx* h, int ld, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
+static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
     const int nf = (int)slots.size();
     const int N = (int)h->csr.N;
-    void* p;
     int rc;
-    std::vector<cplx*> abs(nf);
-    std::vector<int*> pvs(nf);
-    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)h->band_factors[slots[q]]; pvs[q] = h->band_pivots[slots[q]]; }
-    if ((rc = fh_get_buf(h, "bd_ptrs", nf * sizeof(cplx*), &p))) return rc;
-    cplx** dabs = (cplx**)p;
-    if ((rc = fh_get_buf(h, "bd_pptrs", nf * sizeof(int*), &p))) return rc;
-    int** dpvs = (int**)p;
-    FH_CHECK(hipMemcpyAsync(dabs, abs.data(), nf * sizeof(cplx*), hipMemcpyHostToDevice, h->stream));
-    FH_CHECK(hipMemcpyAsync(dpvs, pvs.data(), nf * sizeof(int*), hipMemcpyHostToDevice, h->stream));
-    FH_CHECK(hipStreamSynchronize(h->stream));
+    cplx** dabs; int** dpvs; int** dperms;
+    if ((rc = band_pointer_arrays(h, slots, &dabs, &dpvs, &dperms))) return rc;
+    if (h->band_plan == 2) {
+        void* p;
+        const size_t bstride = (size_t)N * ld;
+        if ((rc = fh_get_buf(h, "bd_ypanel", (size_t)nf * bstride * sizeof(cplx), &p))) return rc;
+        cplx* Yb = (cplx*)p;
+        if ((rc = fh_get_buf(h, "bd_zpanel", (size_t)nf * bstride * sizeof(cplx), &p))) return rc;
+        cplx* Zb = (cplx*)p;
+        return fh_wband_solve(h, nf, dabs, dpvs, dperms, h->band_perm, RHS, Y, stride, Yb, Zb, ld, m, h->band_kl, h->band_ku);
+    }
     fh_prof_begin(h, "band_solve");
     const size_t total = (size_t)N * ld;
     hipLaunchKernelGGL(k_band_copy_rhs, dim3((unsigned)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048), nf), dim3(FH_BLOCK), 0, h->stream, RHS, Y, stride, total);
-    hipLaunchKernelGGL(k_band_solve, dim3(ld / 16, nf), dim3(FH_BLOCK), 0, h->stream, dabs, dpvs, Y, stride, N, ld, h->csr_kl, h->csr_ku);
+    hipLaunchKernelGGL(k_band_solve, dim3(ld / 16, nf), dim3(FH_BLOCK), 0, h->stream, dabs, dpvs, Y, stride, N, ld, h->band_kl, h->band_ku);
     fh_prof_end(h);
     return 0;
 }
 
 int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, cplx* Y,
                           size_t stride, std::vector<int>& status, int64_t* nfact) {
-    (void)m;
     int rc = band_check(h);
     if (rc) return rc;
     if ((rc = band_ensure_slots(h, nodes))) return rc;
@@ -278,14 +367,13 @@ int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::
     if (nfact) *nfact = (int64_t)need.size();
     std::vector<int> slots(nodes);
     for (int e = 0; e < nodes; ++e) slots[e] = e;
-    if ((rc = band_solve_batch(h, ld, slots, RHS, Y, stride))) return rc;
+    if ((rc = band_solve_batch(h, ld, m, slots, RHS, Y, stride))) return rc;
     status.assign(nodes, 0);
     for (int e = 0; e < nodes; ++e) if (h->band_valid[e] != 1) status[e] = FEASTHIP_ERROR_LAPACK;
     return 0;
 }
 
 int fh_banded_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status, int64_t* nfact) {
-    (void)m;
     int rc = band_check(h);
     if (rc) return rc;
     int slot = h->node_count;           // a shift equal to a local quadrature node reuses that node's factor
@@ -303,7 +391,18 @@ int fh_banded_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* R
         h->band_valid[slot] = info[0] == 0 ? 1 : -1;
         if (nfact) *nfact = 1;
     }
-    if ((rc = band_solve_batch(h, ld, need, RHS, Y, (size_t)h->csr.N * ld))) return rc;
+    if ((rc = band_solve_batch(h, ld, m, need, RHS, Y, (size_t)h->csr.N * ld))) return rc;
     *status = h->band_valid[slot] == 1 ? 0 : FEASTHIP_ERROR_LAPACK;
     return 0;
+}
+
+// The band the direct solver would work on, and the device memory one factor takes (feasthip_band_plan)
+int fh_banded_plan(feasthip_ctx* h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked) {
+    int rc = band_check(h);
+    if (rc && !h->band_plan) return rc;
+    if (kl) *kl = h->band_kl;
+    if (ku) *ku = h->band_ku;
+    if (bytes_per_node) *bytes_per_node = (int64_t)band_slot_bytes(h);
+    if (blocked) *blocked = h->band_plan == 2 ? 1 : 0;
+    return rc;
 }

@@ -170,6 +170,13 @@ struct feasthip_ctx {
     int lu_prec = 64;             // element type of the cached dense factors: 64 = complex128, 32 = complex64
     // banded LU (CSR input, FEASTHIP_SOLVER_BANDED): bandwidths of the union pattern, factors per node slot
     int csr_kl = 0, csr_ku = 0;
+    // pattern of the matrix as stored on the device (ingest order), kept on the host for the band plan of the direct solver
+    std::vector<int> host_rowptr, host_col;
+    // band plan (fh_banded.hip): 0 not made, 1 narrow band in stored order (one-workgroup elimination), 2 blocked band LU
+    // on the dense kernels in band order (band_perm[band row] = stored row, band_iperm its inverse; both on the device)
+    int band_plan = 0, band_kl = 0, band_ku = 0;
+    int* band_perm = nullptr;
+    int* band_iperm = nullptr;
     std::vector<void*> band_factors;
     std::vector<int*> band_pivots;
     std::vector<int> band_valid;

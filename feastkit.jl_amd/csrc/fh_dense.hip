@@ -315,6 +315,16 @@ template <> struct lu_el<cplxf> {
     __device__ static v4 mfma(float a, float b, v4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 };
 #define LU_MK(a, b) lu_el<T>::mk((a), (b))
+// Geometry of a factor the LU / substitution kernels work on.  Dense factor: ld = n = N, the inverted diagonal blocks sit
+// behind the N x N matrix.  Band factor (fh_wband_*, below): the SAME kernels run on general band storage viewed as a
+// column-major matrix with leading dimension ldab - 1 (element (i, j) of the band at base + i + j (ldab - 1)), n = matrix
+// order for the row / column bounds, and the inverses behind the band array.
+struct lu_geom {
+    int ld;             // leading dimension of the column-major view
+    int n;              // rows = columns of the matrix (bounds)
+    size_t inv32;       // offset (elements, from the matrix pointer) of the LU_NB-block inverses
+    size_t inv128;      // offset of the SOLVE_KB-block inverses
+};
 template <typename VT, bool BIDENT, typename T>
 __global__ __launch_bounds__(FH_BLOCK) void k_form_shifted(const VT* __restrict__ A, const VT* __restrict__ B,
                                                             T* const* LUs, const cplx* z, int N) {
@@ -443,9 +453,10 @@ __device__ inline void lu_wave_argmax(double& best, int& bi) {
 // Pivot rule as k_lu_panel (LAPACK IZAMAX).  Each panel entry is read from and written to
 // global memory once per sub-panel it participates in, instead of once per column.
 template <int R, int W, typename T>
-__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs, int* const* pivs, int N, int k0,
+__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs, int* const* pivs, lu_geom g, int nr, int k0,
                                                                     int nb, int* info) {
     T* A = LUs[blockIdx.x];
+    const int N = g.ld;                          // leading dimension; rows of the panel: [k0, nr)
     int* piv = pivs[blockIdx.x];
     __shared__ double wmax[LU_PANEL_THREADS / 64];
     __shared__ int widx[LU_PANEL_THREADS / 64];
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int w = 0; w < W; ++w)
-                a[r][w] = (rows[r] >= c0 && rows[r] < N && w < wact) ? A[(size_t)(c0 + w) * N + rows[r]] : LU_MK(0, 0);
+                a[r][w] = (rows[r] >= c0 && rows[r] < nr && w < wact) ? A[(size_t)(c0 + w) * N + rows[r]] : LU_MK(0, 0);
         // The loop is bound by the latency of these streaming loads of L, not by their bytes.  complex64 has the
         // registers for two previous columns per step (pc is a multiple of W, so even); complex128 at 1024 threads
         // (128 VGPRs) does not -- the two-column form spilled -- and keeps one column per step.
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                 T l0[R], l1[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const bool own = rows[r] >= c0 && rows[r] < N;
+                    const bool own = rows[r] >= c0 && rows[r] < nr;
                     l0[r] = own ? A[(size_t)(k0 + p) * N + rows[r]] : LU_MK(0, 0);
                     l1[r] = own ? A[(size_t)(k0 + p + 1) * N + rows[r]] : LU_MK(0, 0);
                 }
@@ -520,7 +531,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
             for (int p = 0; p < pc; ++p) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (rows[r] >= c0 && rows[r] < N) {
+                    if (rows[r] >= c0 && rows[r] < nr) {
                         const T l = A[(size_t)(k0 + p) * N + rows[r]];
 #pragma unroll
                         for (int w = 0; w < W; ++w) a[r][w] = csub(a[r][w], cmul(l, Us[p][w]));
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                 int bi = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (rows[r] >= jj && rows[r] < N) {
+                    if (rows[r] >= jj && rows[r] < nr) {
                         const double m = fabs(a[r][j].x) + fabs(a[r][j].y);
                         if (m > best) { best = m; bi = rows[r]; }
                     }
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                             for (int w = 0; w < W; ++w) a[r][w] = rowA[w];
                         }
                     }
-                    if (rows[r] > jj && rows[r] < N) {
+                    if (rows[r] > jj && rows[r] < nr) {
                         const T l = cmul(a[r][j], inv);
                         a[r][j] = l;
 #pragma unroll
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int w = 0; w < W; ++w)
-                if (rows[r] >= c0 && rows[r] < N && w < wact) A[(size_t)(c0 + w) * N + rows[r]] = a[r][w];
+                if (rows[r] >= c0 && rows[r] < nr && w < wact) A[(size_t)(c0 + w) * N + rows[r]] = a[r][w];
         __syncthreads();
     }
     // ---- inverse of the unit-lower diagonal block, for the U block row (k_lu_trsm_mul): column c of L11^-1 by forward
@@ -614,7 +625,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
             Lsm[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
         }
         __syncthreads();
-        T* inv = A + (size_t)N * N + (size_t)(k0 / LU_NB) * 2 * LU_NB * LU_NB;
+        T* inv = A + g.inv32 + (size_t)(k0 / LU_NB) * 2 * LU_NB * LU_NB;
         for (int c = wave; c < LU_NB; c += LU_PANEL_THREADS / 64) {
             T x = LU_MK(lane == c ? 1.0 : 0.0, 0.0);
             for (int i = c; i + 1 < LU_NB; ++i) {
@@ -674,11 +685,12 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm(T* const* LUs, int N, int 
 // A[k0:k0+NB, c] = L11^-1 A[k0:k0+NB, c].  One thread per ENTRY (NB rows x 8 columns per workgroup): 32 independent
 // multiply-adds instead of the substitution's 31 dependent steps per thread, coalesced 512 B column segments.
 template <int NB, typename T>
-__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm_mul(T* const* LUs, int N, int k0, int c0, int c1) {
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm_mul(T* const* LUs, lu_geom g, int k0, int c0, int c1) {
     static_assert(FH_BLOCK % NB == 0, "rows x columns tiling");
     constexpr int CW = FH_BLOCK / NB;
     T* A = LUs[blockIdx.y];
-    const T* inv = A + (size_t)N * N + (size_t)(k0 / NB) * 2 * NB * NB;
+    const int N = g.ld;
+    const T* inv = A + g.inv32 + (size_t)(k0 / NB) * 2 * NB * NB;
     __shared__ T Li[NB * NB];          // column-major: Li[j * NB + i], lanes read consecutive i
     __shared__ T a[CW][NB];
     const int t = threadIdx.x, i = t % NB, cc = t / NB;
@@ -977,11 +989,12 @@ __global__ void k_build_perm_global(int* const* pivs, int N) {
 // block.  The block triangular solves then become products (k_solve_step), which removes the
 // nb-step sequential substitution from the critical path of every block step.
 template <int NB, typename T>
-__global__ __launch_bounds__(64) void k_lu_invert_diag(T* const* LUs, int N) {
+__global__ __launch_bounds__(64) void k_lu_invert_diag(T* const* LUs, lu_geom g) {
     T* A = LUs[blockIdx.y];
+    const int N = g.ld;
     const int k0 = blockIdx.x * NB;
-    const int nb = min(NB, N - k0);
-    T* inv = A + (size_t)N * N + (size_t)blockIdx.x * 2 * NB * NB;
+    const int nb = min(NB, g.n - k0);
+    T* inv = A + g.inv32 + (size_t)blockIdx.x * 2 * NB * NB;
     __shared__ T Tb[NB][NB + 1];
     __shared__ T Li[NB][NB + 1];
     __shared__ T Ui[NB][NB + 1];
@@ -1145,12 +1158,16 @@ __host__ __device__ inline size_t lu_inv128_offset(int N) {
     return (size_t)N * N + (size_t)((N + LU_NB - 1) / LU_NB) * 2 * LU_NB * LU_NB;
 }
 
+template <typename T>
+static inline lu_geom lu_dense_geom(int N) { return lu_geom{N, N, (size_t)N * N, lu_inv128_offset<T>(N)}; }
+
 template <int LD, bool UPPER, bool IDENT, typename T>
-__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T* OUT, size_t stride, int N, int K0, int kb) {
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T* OUT, size_t stride, lu_geom g, int K0, int kb) {
     const int node = IDENT ? blockIdx.z : blockIdx.y;
     const T* A = LUs[node];
-    const T* invbase = A + (size_t)N * N;
-    if (IDENT) { K0 = blockIdx.y * SOLVE_KB; kb = min(SOLVE_KB / LU_NB, (N - K0 + LU_NB - 1) / LU_NB); }
+    const int N = g.ld, NBND = g.n;
+    const T* invbase = A + g.inv32;
+    if (IDENT) { K0 = blockIdx.y * SOLVE_KB; kb = min(SOLVE_KB / LU_NB, (NBND - K0 + LU_NB - 1) / LU_NB); }
     const T* in = IN + (size_t)node * stride;
     T* out = OUT + (size_t)node * stride;
     const int ta = blockIdx.x;
@@ -1160,7 +1177,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
     for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
         const int i = e >> 4, c = e & 15, row = K0 + i;
         if (IDENT) S[i][c] = LU_MK(i == 16 * ta + c ? 1.0 : 0.0, 0.0);
-        else S[i][c] = (i < LU_NB * kb && row < N) ? in[(size_t)row * LD + 16 * ta + c] : LU_MK(0, 0);
+        else S[i][c] = (i < LU_NB * kb && row < NBND) ? in[(size_t)row * LD + 16 * ta + c] : LU_MK(0, 0);
     }
     __syncthreads();
     for (int step = 0; step < kb; ++step) {
@@ -1193,7 +1210,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
 #pragma unroll
             for (int kk = 0; kk < LU_NB; kk += 4) {
                 const int grow = K0 + rbase + lr, gcol = k0 + kk + lk;
-                const T a = (grow < N && gcol < N) ? A[(size_t)gcol * N + grow] : LU_MK(0, 0);
+                const T a = (grow < NBND && gcol < NBND) ? A[(size_t)gcol * N + grow] : LU_MK(0, 0);
                 const T b = S[LU_NB * i + kk + lk][lr];
                 ur = lu_el<T>::mfma(a.x, b.x, ur);
                 ur = lu_el<T>::mfma(-a.y, b.y, ur);
@@ -1209,7 +1226,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
         __syncthreads();
     }
     if (IDENT) {
-        T* inv128 = LUs[node] + lu_inv128_offset<T>(N) + ((size_t)blockIdx.y * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
+        T* inv128 = LUs[node] + g.inv128 + ((size_t)blockIdx.y * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
         for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
             const int i = e & (SOLVE_KB - 1), c = e / SOLVE_KB;
             inv128[(size_t)(16 * ta + c) * SOLVE_KB + i] = S[i][c];
@@ -1218,7 +1235,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
     }
     for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
         const int i = e >> 4, c = e & 15, row = K0 + i;
-        if (i < LU_NB * kb && row < N) out[(size_t)row * LD + 16 * ta + c] = S[i][c];
+        if (i < LU_NB * kb && row < NBND) out[(size_t)row * LD + 16 * ta + c] = S[i][c];
     }
 }
 
@@ -1227,9 +1244,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
 // 16-blocks together for every wave, and issues all nine operand loads before the slab is even in LDS: the
 // kernel sits on the critical path of the substitution and is pure latency.
 template <int LD, bool UPPER, typename T>
-__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag_inv(T* const* LUs, T* IN, T* OUT, size_t stride, int N, int K0, int kb) {
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_diag_inv(T* const* LUs, T* IN, T* OUT, size_t stride, lu_geom g, int K0, int kb) {
     constexpr int NT = SOLVE_KB / 16;
-    const T* inv = LUs[blockIdx.y] + lu_inv128_offset<T>(N) + ((size_t)(K0 / SOLVE_KB) * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
+    const T* inv = LUs[blockIdx.y] + g.inv128 + ((size_t)(K0 / SOLVE_KB) * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
     const T* in = IN + (size_t)blockIdx.y * stride;
     T* out = OUT + (size_t)blockIdx.y * stride;
     const int ta = blockIdx.x;
@@ -1248,7 +1265,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag_inv(T* const* LUs, T* I
     }
     for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
         const int i = e >> 4, c = e & 15, row = K0 + i;
-        S[i][c] = (i < LU_NB * kb && row < N) ? in[(size_t)row * LD + 16 * ta + c] : LU_MK(0, 0);
+        S[i][c] = (i < LU_NB * kb && row < g.n) ? in[(size_t)row * LD + 16 * ta + c] : LU_MK(0, 0);
     }
     __syncthreads();
     typename lu_el<T>::v4 re0 = {0, 0, 0, 0}, im0 = {0, 0, 0, 0}, re1 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0};
@@ -1274,19 +1291,20 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag_inv(T* const* LUs, T* I
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i0 = 16 * t0 + lu_el<T>::mrow(lk, r), i1 = 16 * t1 + lu_el<T>::mrow(lk, r);
-        if (i0 < LU_NB * kb && K0 + i0 < N) out[(size_t)(K0 + i0) * LD + 16 * ta + lr] = LU_MK(re0[r], im0[r]);
-        if (i1 < LU_NB * kb && K0 + i1 < N) out[(size_t)(K0 + i1) * LD + 16 * ta + lr] = LU_MK(re1[r], im1[r]);
+        if (i0 < LU_NB * kb && K0 + i0 < g.n) out[(size_t)(K0 + i0) * LD + 16 * ta + lr] = LU_MK(re0[r], im0[r]);
+        if (i1 < LU_NB * kb && K0 + i1 < g.n) out[(size_t)(K0 + i1) * LD + 16 * ta + lr] = LU_MK(re1[r], im1[r]);
     }
 }
 
 template <int LD, typename T>
-__global__ __launch_bounds__(FH_BLOCK) void k_solve_update(T* const* LUs, T* IN, const T* ZS, size_t stride, int N, int K0,
+__global__ __launch_bounds__(FH_BLOCK) void k_solve_update(T* const* LUs, T* IN, const T* ZS, size_t stride, lu_geom g, int K0,
                                                             int kd, int r0, int r1, int cta) {
     typedef decltype(T().x) ET;
     constexpr int KC = SOLVE_KC, CT = LD / 16, XPT = KC * LD / FH_BLOCK;
     __shared__ ET Xre[KC][LD + 16];
     __shared__ ET Xim[KC][LD + 16];
     const T* A = LUs[blockIdx.y];
+    const int N = g.ld;
     T* in = IN + (size_t)blockIdx.y * stride;
     const T* zs = ZS + (size_t)blockIdx.y * stride;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1301,13 +1319,13 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_update(T* const* LUs, T* IN,
 #pragma unroll
         for (int q = 0; q < XPT; ++q) {
             const int e = t + q * FH_BLOCK, jj = e / LD, c = e % LD;
-            const bool ok = j0 + jj < kd && K0 + j0 + jj < N;
+            const bool ok = j0 + jj < kd && K0 + j0 + jj < g.n;
             xn[q] = ok ? zs[(size_t)(K0 + j0 + jj) * LD + c] : LU_MK(0, 0);
         }
 #pragma unroll
         for (int s = 0; s < KC / 4; ++s) {
             const int jk = j0 + 4 * s + lk, col = K0 + jk;
-            an[s] = (irow < r1 && jk < kd && col < N) ? A[(size_t)col * N + irow] : LU_MK(0, 0);
+            an[s] = (irow < r1 && jk < kd && col < g.n) ? A[(size_t)col * N + irow] : LU_MK(0, 0);
         }
     };
     load_chunk(0);
@@ -1361,6 +1379,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     const int nf = (int)which.size();
     if (nf == 0) return 0;
     const int N = (int)h->dense.N;
+    const lu_geom geom = lu_dense_geom<T>(N);
     void* p;
     int rc;
     std::vector<T*> lus(nf);
@@ -1411,7 +1430,7 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         if (c1 <= c0) return;
         fh_prof_begin(h, "lu_trsm");
         if (!trsm_subst && panel_in_registers(k0) && k0 + LU_NB <= N)
-            hipLaunchKernelGGL((k_lu_trsm_mul<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK / LU_NB - 1) / (FH_BLOCK / LU_NB), nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
+            hipLaunchKernelGGL((k_lu_trsm_mul<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK / LU_NB - 1) / (FH_BLOCK / LU_NB), nf), dim3(FH_BLOCK), 0, h->stream, dlus, geom, k0, c0, c1);
         else
             hipLaunchKernelGGL((k_lu_trsm<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, c0, c1);
         fh_prof_end(h);
@@ -1503,11 +1522,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
                 const int nrows = N - k0;
                 const dim3 g(nf), b(LU_PANEL_THREADS);
                 if (!panel_in_registers(k0)) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
+                else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
+                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
+                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
+                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
+                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
             }
             fh_prof_end(h);
             // interchanges inside the block column (left: finished L columns, right: still to eliminate)
@@ -1550,11 +1569,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     }
     if (rest_pending) FH_CHECK(hipStreamWaitEvent(main_s, h->lu_ev_rest, 0));
     fh_prof_begin(h, "lu_invert");
-    hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, N);
+    hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dlus, geom);
     {   // 128 x 128 inverses from the 32-block inverses: the in-block substitution applied to the identity
         dim3 g(SOLVE_KB / 16, (N + SOLVE_KB - 1) / SOLVE_KB, nf);
-        hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dlus, (T*)nullptr, (T*)nullptr, (size_t)0, N, 0, 0);
-        hipLaunchKernelGGL((k_solve_diag<16, true, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dlus, (T*)nullptr, (T*)nullptr, (size_t)0, N, 0, 0);
+        hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dlus, (T*)nullptr, (T*)nullptr, (size_t)0, geom, 0, 0);
+        hipLaunchKernelGGL((k_solve_diag<16, true, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dlus, (T*)nullptr, (T*)nullptr, (size_t)0, geom, 0, 0);
     }
     if (N <= 16000) hipLaunchKernelGGL(k_build_perm, dim3(nf), dim3(FH_BLOCK), (size_t)N * sizeof(int), h->stream, dpvs, N);
     else hipLaunchKernelGGL(k_build_perm_global, dim3(nf), dim3(64), 0, h->stream, dpvs, N);
@@ -1575,6 +1594,7 @@ static int lu_solve_rb(int rows, int nf) {
 template <int LD, typename T>
 static void lu_solve_launch(feasthip_ctx* h, T** dlus, T* Y, T* Z, size_t stride, int N, int nf, int m) {
     const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
+    const lu_geom geom = lu_dense_geom<T>(N);
     const int nblocks = (N + LU_NB - 1) / LU_NB;
     const bool one_level = h->lu_solve_legacy != 0;
     if (!one_level) {
@@ -1582,17 +1602,17 @@ static void lu_solve_launch(feasthip_ctx* h, T** dlus, T* Y, T* Z, size_t stride
         for (int b = 0; b < nouter; ++b) {        // forward: L z = P b   (Y -> Z)
             const int K0 = b * SOLVE_KB, kb = std::min(SOLVE_KB / LU_NB, (N - K0 + LU_NB - 1) / LU_NB);
             const int r0 = K0 + LU_NB * kb;
-            hipLaunchKernelGGL((k_solve_diag_inv<LD, false, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, N, K0, kb);
+            hipLaunchKernelGGL((k_solve_diag_inv<LD, false, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z, stride, geom, K0, kb);
             if (r0 < N)
                 hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((N - r0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Y, Z,
-                                   stride, N, K0, LU_NB * kb, r0, N, cta);
+                                   stride, geom, K0, LU_NB * kb, r0, N, cta);
         }
         for (int b = nouter - 1; b >= 0; --b) {   // backward: U x = z   (Z -> Y)
             const int K0 = b * SOLVE_KB, kb = std::min(SOLVE_KB / LU_NB, (N - K0 + LU_NB - 1) / LU_NB);
-            hipLaunchKernelGGL((k_solve_diag_inv<LD, true, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, N, K0, kb);
+            hipLaunchKernelGGL((k_solve_diag_inv<LD, true, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y, stride, geom, K0, kb);
             if (K0 > 0)
                 hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((K0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dlus, Z, Y,
-                                   stride, N, K0, LU_NB * kb, 0, K0, cta);
+                                   stride, geom, K0, LU_NB * kb, 0, K0, cta);
         }
         return;
     }
@@ -1723,5 +1743,252 @@ int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx*
     if ((rc = f32 ? lu_solve_batch<cplxf>(h, ld, m, need, RHS, 0, Y, (size_t)h->dense.N * ld)
                   : lu_solve_batch<cplx>(h, ld, m, need, RHS, 0, Y, (size_t)h->dense.N * ld))) return rc;
     *status = h->lu_valid[slot] == 1 ? 0 : FEASTHIP_ERROR_LAPACK;
+    return 0;
+}
+
+// =======================================================================================
+// Blocked band LU on the dense kernels: the sparse DIRECT solver for patterns whose band (after the reverse
+// Cuthill-McKee renumbering of fh_ingest.hpp) is too wide for the one-workgroup-per-node elimination of fh_banded.hip.
+// Reference: the sparse drivers' default `lu(z B - A)` (UMFPACK, src/sparse/feast_sparse.jl:339, 342; parallel workers
+// src/parallel/feast_parallel.jl:603-613, 728-735) -- a direct factorisation per quadrature node, cached across refinement
+// loops.  UMFPACK's multifrontal elimination is replaced by a band elimination (same arithmetic class: Gaussian
+// elimination with partial pivoting, fill confined to the band instead of the elimination tree).
+//
+// Storage per node: general band storage with room for the blocks,
+//     AB(ldab, N),  ldab = 2 kl + ku + 2 WB,  A(i, j) = AB[kvp + i - j + j ldab],  kvp = kl + ku + WB,  WB = 128,
+// i.e. LAPACK's ZGBTRF layout with WB extra rows above and below.  Seen through the pointer base = AB + kvp and the leading
+// dimension ldab - 1 this is an ordinary column-major matrix, A(i, j) = base[i + j (ldab - 1)], in which every entry of the
+// window of block column [K0, K0 + WB) -- rows up to K0 + WB + kl, columns up to K0 + WB + kl + ku -- has its own storage
+// cell (entries outside band + fill are zeros that stay zero).  The elimination is therefore the dense two-level LU of this
+// file restricted to that window: the register-resident panels, the MFMA trailing update, the inverted diagonal blocks, all
+// unchanged, told the geometry through lu_geom.  As in ZGBTRF the interchanges of a block column are NOT applied to the
+// block columns left of it; the substitution applies them block by block (k_wband_swap).
+// Work: 8 N kl (kl + ku) flop per node (cfg 3 after RCM: kl = ku = 951, 7.2e11), storage 16 N ldab bytes (2.5 GB).
+// =======================================================================================
+#define WB 128
+static_assert(WB == SOLVE_KB && WB % LU_NB == 0, "factor blocks = substitution blocks");
+
+struct wband_geom { int N, kl, ku, ldab, kvp; lu_geom g; size_t elems; };
+static wband_geom wband_geometry(int N, int kl, int ku) {
+    wband_geom w;
+    w.N = N; w.kl = kl; w.ku = ku;
+    w.ldab = 2 * kl + ku + 2 * WB;
+    w.kvp = kl + ku + WB;
+    const size_t nblk32 = ((size_t)N + LU_NB - 1) / LU_NB, nblk128 = ((size_t)N + SOLVE_KB - 1) / SOLVE_KB;
+    w.g.ld = w.ldab - 1;
+    w.g.n = N;
+    w.g.inv32 = (size_t)w.ldab * N - w.kvp;
+    w.g.inv128 = w.g.inv32 + nblk32 * 2 * LU_NB * LU_NB;
+    w.elems = (size_t)w.ldab * N + nblk32 * 2 * LU_NB * LU_NB + nblk128 * 2 * SOLVE_KB * SOLVE_KB;
+    return w;
+}
+size_t fh_wband_elems(int N, int kl, int ku) { return wband_geometry(N, kl, ku).elems; }
+size_t fh_wband_base_offset(int N, int kl, int ku) { return (size_t)wband_geometry(N, kl, ku).kvp; }
+
+// base[i' + j' ld] = z B - A for the renumbered unknowns i' = iperm[i] (iperm null: as stored); the storage was zeroed
+template <typename VT, bool BIDENT>
+__global__ __launch_bounds__(FH_BLOCK) void k_wband_form(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          const VT* __restrict__ aval, const VT* __restrict__ bval,
+                                                          cplx* const* bases, const cplx* z, const int* __restrict__ iperm, int N, int ld) {
+    cplx* base = bases[blockIdx.y];
+    const cplx zz = z[blockIdx.y];
+    const int i = blockIdx.x * FH_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const int bi = iperm ? iperm[i] : i;
+    if (BIDENT) base[(size_t)bi * ld + bi] = zz;
+    for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int bj = iperm ? iperm[col[k]] : col[k];
+        cplx a;
+        if constexpr (sizeof(VT) == sizeof(cplx)) a = cmake(aval[k].x, aval[k].y); else a = cmake(aval[k], 0.0);
+        cplx* dst = base + (size_t)bj * ld + bi;
+        if (BIDENT) {
+            *dst = csub(*dst, a);
+        } else {
+            cplx b;
+            if constexpr (sizeof(VT) == sizeof(cplx)) b = cmake(bval[k].x, bval[k].y); else b = cmake(bval[k], 0.0);
+            *dst = csub(cmul(zz, b), a);
+        }
+    }
+}
+
+// The row interchanges piv[K0 .. K0 + nbk) of one block column applied to the rows [K0, K0 + W) of row-major panels:
+// the swaps are composed on row INDICES in LDS (one thread, nbk short steps), the (at most 2 nbk) rows that end up
+// somewhere else are read by all threads into registers and written to their places.  grid (ld / 16, nodes).
+__global__ __launch_bounds__(FH_BLOCK) void k_wband_swap(int* const* pivs, cplx* Y, size_t stride, int ld, int K0, int nbk, int W) {
+    extern __shared__ int wb_cur[];          // [W] original row (relative to K0) now at position i
+    __shared__ int s_dst[2 * WB], s_src[2 * WB];
+    __shared__ int s_cnt;
+    const int* piv = pivs[blockIdx.y] + K0;
+    cplx* Yn = Y + (size_t)blockIdx.y * stride + 16 * blockIdx.x;
+    const int t = threadIdx.x;
+    for (int i = t; i < W; i += FH_BLOCK) wb_cur[i] = i;
+    if (t == 0) s_cnt = 0;
+    __syncthreads();
+    if (t == 0) {
+        for (int j = 0; j < nbk; ++j) {
+            const int p = piv[j] - K0;
+            if (p != j && p >= 0 && p < W) { const int u = wb_cur[j]; wb_cur[j] = wb_cur[p]; wb_cur[p] = u; }
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < W; i += FH_BLOCK) {
+        if (wb_cur[i] != i) { const int q = atomicAdd(&s_cnt, 1); if (q < 2 * WB) { s_dst[q] = i; s_src[q] = wb_cur[i]; } }
+    }
+    __syncthreads();
+    const int cnt = min(s_cnt, 2 * WB);
+    const int c = t & 15, rr = t >> 4;
+    constexpr int RL = FH_BLOCK / 16, NV = 2 * WB / RL;
+    cplx v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int e = rr + q * RL;
+        v[q] = e < cnt ? Yn[(size_t)(K0 + s_src[e]) * ld + c] : cmake(0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int e = rr + q * RL;
+        if (e < cnt) Yn[(size_t)(K0 + s_dst[e]) * ld + c] = v[q];
+    }
+}
+
+// Y[node][perm[i], :] = Yb[node][i, :]
+__global__ __launch_bounds__(FH_BLOCK) void k_scatter_rows(const cplx* __restrict__ Yb, size_t bstride, const int* __restrict__ perm,
+                                                            cplx* __restrict__ Y, size_t stride, int N, int ld) {
+    const cplx* s = Yb + (size_t)blockIdx.y * bstride;
+    cplx* d = Y + (size_t)blockIdx.y * stride;
+    const size_t total = (size_t)N * ld;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const size_t i = e / ld, c = e % ld;
+        d[(size_t)(perm ? perm[i] : (int)i) * ld + c] = s[e];
+    }
+}
+
+// Form z B - A in band storage (zeroed here) and factor it, nf nodes at once.  dabs: device array of the nf storage pointers
+// (AB, not base), dbases: the same plus kvp; dpvs: pivots (N ints per node, global row indices); info_out[q] = 0 or the
+// 1-based column of a zero pivot.
+int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbases, int** dpvs, const cplx* dz, int* dinfo,
+                    const int* d_iperm, int kl, int ku) {
+    typedef cplx T;
+    const int N = (int)h->csr.N;
+    const wband_geom w = wband_geometry(N, kl, ku);
+    const lu_geom geom = w.g;
+    const int lda = geom.ld;
+    fh_prof_begin(h, "wband_form");
+    for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(abs_host[q], 0, (size_t)w.ldab * N * sizeof(cplx), h->stream));
+    {
+        const dim3 grid((N + FH_BLOCK - 1) / FH_BLOCK, nf), block(FH_BLOCK);
+        const bool bid = h->csr.b_identity != 0;
+        if (h->csr.is_complex) {
+            if (bid) hipLaunchKernelGGL((k_wband_form<cplx, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)nullptr, dbases, dz, d_iperm, N, lda);
+            else hipLaunchKernelGGL((k_wband_form<cplx, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dbases, dz, d_iperm, N, lda);
+        } else {
+            if (bid) hipLaunchKernelGGL((k_wband_form<double, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)nullptr, dbases, dz, d_iperm, N, lda);
+            else hipLaunchKernelGGL((k_wband_form<double, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)h->csr.bval, dbases, dz, d_iperm, N, lda);
+        }
+    }
+    fh_prof_end(h);
+    fh_prof_begin(h, "wband_lu");
+    auto laswp = [&](int p0, int np, int a0, int a1, int b0, int b1) {
+        const int ncols = (a1 - a0) + (b1 - b0);
+        if (ncols <= 0) return;
+        hipLaunchKernelGGL((k_lu_laswp<T>), dim3((ncols + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dbases, dpvs, lda, p0, np, a0, a1, b0, b1);
+    };
+    auto trsm = [&](int k0, int nb, int c0, int c1) {
+        if (c1 <= c0) return;
+        if (nb == LU_NB)
+            hipLaunchKernelGGL((k_lu_trsm_mul<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK / LU_NB - 1) / (FH_BLOCK / LU_NB), nf), dim3(FH_BLOCK), 0, h->stream, dbases, geom, k0, c0, c1);
+        else
+            hipLaunchKernelGGL((k_lu_trsm<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK - 1) / FH_BLOCK, nf), dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, c0, c1);
+    };
+    static const bool m3_off = getenv("FH_LU_3M") && atoi(getenv("FH_LU_3M")) == 0;
+    auto gemm = [&](int k0, int kd, int r0, int r1, int c0, int c1) {
+        if (r1 <= r0 || c1 <= c0) return;
+        if (h->profiling) h->prof_work["wband_lu"] += 8.0 * (double)(r1 - r0) * (double)(c1 - c0) * (double)kd * (double)nf;
+        const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
+        const int sw = std::min(8, TC);
+        const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
+        const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nf);
+        if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
+        else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
+    };
+    for (int K0 = 0; K0 < N; K0 += WB) {
+        const int Kend = std::min(N, K0 + WB);
+        const int nr = std::min(N, Kend + kl);                 // rows the block column reaches
+        const int nc = std::min(N, Kend + kl + ku);            // columns its pivot rows reach
+        for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
+            const int nb = std::min(LU_NB, Kend - k0);
+            const int nrows = nr - k0;
+            const dim3 g(nf), b(LU_PANEL_THREADS);
+            if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
+            else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
+            else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
+            else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
+            else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
+            laswp(k0, nb, K0, k0, k0 + nb, Kend);              // inside the block column only
+            if (k0 + nb < Kend) {
+                trsm(k0, nb, k0 + nb, Kend);
+                gemm(k0, LU_NB, k0 + nb, nr, k0 + nb, Kend);
+            }
+        }
+        if (Kend >= N) break;
+        laswp(K0, Kend - K0, 0, 0, Kend, nc);                  // to the right; never to the left (ZGBTRF)
+        for (int k0 = K0; k0 < Kend; k0 += LU_NB) {            // Kend - K0 == WB here
+            trsm(k0, LU_NB, Kend, nc);
+            gemm(k0, LU_NB, k0 + LU_NB, Kend, Kend, nc);
+        }
+        gemm(K0, WB, Kend, nr, Kend, nc);
+    }
+    hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dbases, geom);
+    {
+        dim3 g(SOLVE_KB / 16, (N + SOLVE_KB - 1) / SOLVE_KB, nf);
+        hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dbases, (T*)nullptr, (T*)nullptr, (size_t)0, geom, 0, 0);
+        hipLaunchKernelGGL((k_solve_diag<16, true, true, T>), g, dim3(FH_BLOCK), 0, h->stream, dbases, (T*)nullptr, (T*)nullptr, (size_t)0, geom, 0, 0);
+    }
+    fh_prof_end(h);
+    (void)dinfo;
+    return 0;
+}
+
+template <int LD>
+static void wband_solve_launch(feasthip_ctx* h, cplx** dbases, int** dpvs, cplx* Y, cplx* Z, size_t stride, const wband_geom& w, int nf, int m) {
+    typedef cplx T;
+    const int N = w.N, kl = w.kl, kv = w.kl + w.ku;
+    const lu_geom geom = w.g;
+    const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
+    const int nouter = (N + SOLVE_KB - 1) / SOLVE_KB;
+    for (int b = 0; b < nouter; ++b) {             // forward: interchanges of the block, L11 z = y, rows below -= L21 z   (Y -> Z)
+        const int K0 = b * SOLVE_KB, Kend = std::min(N, K0 + SOLVE_KB);
+        const int kb = (Kend - K0 + LU_NB - 1) / LU_NB;
+        const int nr = std::min(N, Kend + kl);
+        hipLaunchKernelGGL(k_wband_swap, dim3(LD / 16, nf), dim3(FH_BLOCK), (size_t)(nr - K0) * sizeof(int), h->stream, dpvs, Y, stride, LD, K0, Kend - K0, nr - K0);
+        hipLaunchKernelGGL((k_solve_diag_inv<LD, false, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dbases, Y, Z, stride, geom, K0, kb);
+        if (Kend < nr)
+            hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((nr - Kend + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dbases, Y, Z, stride, geom, K0, Kend - K0, Kend, nr, cta);
+    }
+    for (int b = nouter - 1; b >= 0; --b) {        // backward: U11 x = z, rows above (within kl + ku) -= U12 x   (Z -> Y)
+        const int K0 = b * SOLVE_KB, Kend = std::min(N, K0 + SOLVE_KB);
+        const int kb = (Kend - K0 + LU_NB - 1) / LU_NB;
+        hipLaunchKernelGGL((k_solve_diag_inv<LD, true, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dbases, Z, Y, stride, geom, K0, kb);
+        const int r0 = std::max(0, K0 - kv);
+        if (r0 < K0)
+            hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((K0 - r0 + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dbases, Z, Y, stride, geom, K0, Kend - K0, r0, K0, cta);
+    }
+}
+
+// Y[node] = (z_node B - A)^-1 RHS with the factors of fh_wband_factor.  RHS: one shared panel (row-major N x ld, the
+// library's row order); d_perm[band row] = library row (null: same order); Yb, Zb: nf work panels in band order.
+int fh_wband_solve(feasthip_ctx* h, int nf, cplx** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, cplx* Y, size_t stride,
+                   cplx* Yb, cplx* Zb, int ld, int m, int kl, int ku) {
+    const int N = (int)h->csr.N;
+    const wband_geom w = wband_geometry(N, kl, ku);
+    const size_t bstride = (size_t)N * ld;
+    fh_prof_begin(h, "wband_solve");
+    hipLaunchKernelGGL((k_gather_rows<cplx>), dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, (size_t)0, dperms, Yb, bstride, N, ld);
+    if (ld == 16) wband_solve_launch<16>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
+    else if (ld == 32) wband_solve_launch<32>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
+    else wband_solve_launch<64>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
+    hipLaunchKernelGGL(k_scatter_rows, dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, Yb, bstride, d_perm, Y, stride, N, ld);
+    fh_prof_end(h);
     return 0;
 }

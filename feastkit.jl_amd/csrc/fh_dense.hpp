@@ -28,3 +28,12 @@ int fh_dense_lu_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std
 // one-off (uncached) solve for a single shift
 int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status,
                              int64_t* nfact);
+
+// Blocked band LU on the dense kernels (fh_dense.hip, "wide band"): storage per node fh_wband_elems complex128 values, the
+// matrix pointer the kernels take is storage + fh_wband_base_offset.
+size_t fh_wband_elems(int N, int kl, int ku);
+size_t fh_wband_base_offset(int N, int kl, int ku);
+int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbases, int** dpvs, const cplx* dz, int* dinfo,
+                    const int* d_iperm, int kl, int ku);
+int fh_wband_solve(feasthip_ctx* h, int nf, cplx** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, cplx* Y, size_t stride,
+                   cplx* Yb, cplx* Zb, int ld, int m, int kl, int ku);

@@ -155,6 +155,74 @@ static void fh_block_partition(int64_t N, const std::vector<int>& rowptr_in, con
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Band plan of the sparse DIRECT solver (fh_banded.hip / fh_dense.hip: blocked band LU on the dense LU kernels).
+// fh_bandwidth: lower / upper band widths of a pattern under a renumbering (iperm[old] = new; null: as stored).
+// fh_rcm: reverse Cuthill-McKee order of the pattern united with its transpose -- every connected component from a
+// pseudo-peripheral vertex (the far end of a breadth-first probe), neighbours taken by increasing degree, the whole order
+// reversed.  perm[new] = old.
+// ---------------------------------------------------------------------------------------
+static void fh_bandwidth(int64_t N, const std::vector<int>& rowptr, const std::vector<int>& col, const int* iperm, int& kl, int& ku) {
+    kl = 0; ku = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int bi = iperm ? iperm[i] : (int)i;
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int bj = iperm ? iperm[col[k]] : col[k];
+            kl = std::max(kl, bi - bj);
+            ku = std::max(ku, bj - bi);
+        }
+    }
+}
+
+static void fh_rcm(int64_t N, const std::vector<int>& rowptr_in, const std::vector<int>& col_in, std::vector<int>& perm) {
+    std::vector<int> rowptr(N + 1, 0), col;
+    {
+        std::vector<int> deg(N, 0);
+        for (int64_t i = 0; i < N; ++i)
+            for (int k = rowptr_in[i]; k < rowptr_in[i + 1]; ++k) if (col_in[k] != i) { deg[i]++; deg[col_in[k]]++; }
+        for (int64_t i = 0; i < N; ++i) rowptr[i + 1] = rowptr[i] + deg[i];
+        col.resize(rowptr[N]);
+        std::vector<int> fill(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t i = 0; i < N; ++i)
+            for (int k = rowptr_in[i]; k < rowptr_in[i + 1]; ++k) {
+                const int j = col_in[k];
+                if (j != i) { col[fill[i]++] = j; col[fill[j]++] = (int)i; }
+            }
+    }
+    // (a symmetric pattern lists every edge twice here; duplicates only cost time in the traversal)
+    std::vector<int> deg(N);
+    for (int64_t i = 0; i < N; ++i) deg[i] = rowptr[i + 1] - rowptr[i];
+    std::vector<int> mark(N, -1), order, probe, nb;
+    order.reserve(N);
+    int id = 0;
+    auto bfs = [&](int start, int tag, std::vector<int>& out, bool by_degree) -> int {
+        const size_t first = out.size();
+        mark[start] = tag;
+        out.push_back(start);
+        for (size_t head = first; head < out.size(); ++head) {
+            const int v = out[head];
+            nb.clear();
+            for (int k = rowptr[v]; k < rowptr[v + 1]; ++k) {
+                const int u = col[k];
+                if (mark[u] != tag && mark[u] != -2) { mark[u] = tag; nb.push_back(u); }
+            }
+            if (by_degree) std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+            for (int u : nb) out.push_back(u);
+        }
+        return out.back();
+    };
+    for (int64_t s = 0; s < N; ++s) {
+        if (mark[s] == -2) continue;                       // -2: placed
+        probe.clear();
+        const int far = bfs((int)s, id++, probe, false);
+        // the probe only marks with a fresh tag; the ordering pass marks placed vertices for good
+        const size_t first = order.size();
+        bfs(far, id++, order, true);
+        for (size_t q = first; q < order.size(); ++q) mark[order[q]] = -2;
+    }
+    perm.assign(order.rbegin(), order.rend());
+}
+
 template <typename VT>
 struct fh_prepared {
     std::vector<int> rowptr, col;              // union pattern, 0-based, (optionally renumbered,) largest column first per row

@@ -363,6 +363,13 @@ class HipEngine:
         self.last_stats = stats.asdict()
         return dY, rc
 
+    def band_plan(self):
+        """(kl, ku, bytes per node, blocked) of the band the direct sparse solver would eliminate (feasthip_band_plan)."""
+        kl, ku, blocked = C.c_int(0), C.c_int(0), C.c_int(0)
+        nbytes = C.c_int64(0)
+        self._chk(self.lib.feasthip_band_plan(self.h, C.byref(kl), C.byref(ku), C.byref(nbytes), C.byref(blocked)))
+        return kl.value, ku.value, nbytes.value, blocked.value
+
     def last_node_iterations(self, n):
         out = np.zeros(max(1, n), dtype=np.int32)
         self._chk(self.lib.feasthip_last_node_iterations(self.h, _np_ptr(out), int(n)))

@@ -56,9 +56,14 @@ enum {
                                       src/interfaces/feast_matfree.jl:716)                 */
     FEASTHIP_SOLVER_GMRES = 2,     /* :gmres   -- batched restarted GMRES(m)
                                       (src/sparse/feast_sparse.jl:183-188)                 */
-    FEASTHIP_SOLVER_BANDED = 4,    /* batched banded LU (ZGBTRF/ZGBTRS) for CSR input with a narrow band: the direct
-                                      solver of the banded drivers (src/banded/feast_banded.jl:100-150) and a
-                                      sparse direct path where the reference uses UMFPACK             */
+    FEASTHIP_SOLVER_BANDED = 4,    /* sparse DIRECT solver for CSR input: batched band LU (ZGBTRF/ZGBTRS semantics,
+                                      partial pivoting) per quadrature node, factors cached across refinement loops.
+                                      The direct solver of the banded drivers (src/banded/feast_banded.jl:100-150) and
+                                      the build's counterpart of the sparse drivers' default `lu(z B - A)` (UMFPACK,
+                                      src/sparse/feast_sparse.jl:339-342): a narrow band is eliminated as stored; any
+                                      other pattern is renumbered by reverse Cuthill-McKee and eliminated by a blocked
+                                      band LU on the dense MFMA kernels (fill confined to the band; memory
+                                      16 N (2 kl + ku + 256) bytes per node -- see feasthip_band_plan)          */
     FEASTHIP_SOLVER_COCG = 3       /* conjugate-orthogonal CG for the complex-SYMMETRIC shifted
                                       systems that real-symmetric A, B produce (one operator
                                       application per iteration); not in the reference      */
@@ -189,6 +194,12 @@ int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
  * BiCGStab/COCG: correction solve on complex64 panels around an fp64 residual (inexact-solve mode).
  * cache_factors: keep LU factors per
  * node across calls (src/dense/feast_dense.jl:147,188).                                 */
+/* The band FEASTHIP_SOLVER_BANDED would eliminate for the current CSR problem (after its reordering) and the device memory
+ * of ONE node's factor; *blocked = 1 when the blocked band LU on the dense kernels is used.  A host shim uses it to decide
+ * between the direct and the iterative solvers (the reference decides by keyword only: src/sparse/feast_sparse.jl:249-252).
+ * Returns 0, FEASTHIP_ERROR_FPM when no CSR problem is set or the band is beyond the solver's reach.                     */
+int  feasthip_band_plan(feasthip_handle h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked);
+
 int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit,
                          int restart, int factor_precision, int cache_factors);
 
