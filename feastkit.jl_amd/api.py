@@ -11,7 +11,7 @@ import scipy.sparse as sp
 from .engine import HipEngine
 from .hip_backend import feast_hip_general, feast_hip_hermitian
 from .parameters import feastdefault, feastinit
-from .types import FEAST_UNINITIALIZED, FeastResult
+from .types import FEAST_UNINITIALIZED, FeastHipError, FeastResult
 
 _BACKENDS = ("hip", "auto")   # _normalize_backend whitelist edit, feast_interfaces.jl:44
 
@@ -46,6 +46,32 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30, dense_limit=12288)
     if N <= dense_limit and (max(nodes, 1) + 2) * N * N * 16 <= budget_bytes:
         return "dense"
     return "krylov"
+
+
+def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False):
+    """True when the sparse direct solver for general patterns (reverse Cuthill-McKee + blocked band LU on the dense
+    kernels, FEASTHIP_SOLVER_BANDED) can hold one factor per local quadrature node in the free device memory.  Sets the
+    problem on the engine (a later set_problem with the same matrices is free: content fingerprint)."""
+    import torch
+    if complexify:
+        A = A.astype(np.complex128) if not np.iscomplexobj(A.data) else A
+        B = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B.data) else B)
+    try:
+        eng.set_problem(A, B)
+        kl, ku, nbytes, blocked = eng.band_plan()
+    except FeastHipError:
+        return False
+    world = 1
+    if group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+    local = -(-max(int(nodes), 1) // world)
+    free, _total = torch.cuda.mem_get_info(eng.device)
+    panels = 2 * local * A.shape[0] * 64 * 16
+    # the elimination costs 8 N kl (kl + ku) flop per node: beyond ~1e14 in all (seconds of MFMA time) a band this wide is no
+    # longer the cheap way to a direct solve
+    flops = 8.0 * A.shape[0] * kl * (kl + ku) * local
+    return (local + 1) * nbytes + panels <= 0.85 * free and flops <= 1e14
 
 
 def _single_precision(*mats):
@@ -176,6 +202,8 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
             if auto:
                 contour_policy = "auto"
                 substituted["contour_policy"] = "auto"
+    if solver == "sparse_direct":
+        solver = "banded"
     warm_start = bool(warm_start)                 # an explicitly named iterative solver keeps the reference's zero guess
     solver_maxiter = 500 if solver_maxiter is None else int(solver_maxiter)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
@@ -183,6 +211,17 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,
                               inner_precision=inner_precision, group=group, Q0=Q0, contour=contour,
                               contour_policy=contour_policy, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
+    if (res.info == 5 and substituted is not None and substituted.get("used") in ("cocg", "bicgstab") and group is None
+            and _band_direct_fits(eng, A, B, int(fpm[2]))):
+        # The Krylov sweeps did not converge (typically an interval inside the spectrum: the shifted systems are then
+        # indefinite and badly conditioned).  solver=:direct was what the caller asked for, and the direct solver for general
+        # patterns fits the device: run it, as the reference's default would have from the start.
+        krylov_info, krylov_loops = int(res.info), int(res.loop)
+        res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver="banded", solver_tol=solver_tol,
+                                  real_projection=real_projection, inner_precision=inner_precision, group=group, Q0=Q0,
+                                  contour=contour, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
+        substituted = dict(substituted, fallback="band LU after reverse Cuthill-McKee", krylov_info=krylov_info,
+                           krylov_loops=krylov_loops)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
     if real_input:
@@ -218,12 +257,22 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
             A, B, solver = _densify(A), _densify(B), "direct"
             substituted = {"requested": "direct", "used": "dense LU of the expanded matrix"}
         elif solver == "krylov":
-            solver = "bicgstab"
-            substituted = {"requested": "direct", "used": solver, "warm_start": False, "inner_rtol": None,
-                           "solver_maxiter": int(solver_maxiter)}
-            _warn_substitution(substituted)
+            # unpreconditioned Krylov sweeps cannot solve shifted systems whose spectrum surrounds the shift (the usual case
+            # for a contour inside a non-Hermitian spectrum): the direct solver for general patterns takes them whenever its
+            # factors fit the device
+            engine = _engine(engine, device)
+            if _band_direct_fits(engine, A, B, int(fpm[8]), group, complexify=True):
+                solver = "banded"
+                substituted = {"requested": "direct", "used": "band LU after reverse Cuthill-McKee"}
+            else:
+                solver = "bicgstab"
+                substituted = {"requested": "direct", "used": solver, "warm_start": False, "inner_rtol": None,
+                               "solver_maxiter": int(solver_maxiter)}
+                _warn_substitution(substituted)
     elif solver == "krylov":
         solver = "bicgstab"
+    elif solver == "sparse_direct":
+        solver = "banded"
     eng = _engine(engine, device)
     res = feast_hip_general(eng, A, B, complex(center), float(radius), M0, fpm, solver=solver, inner_precision=inner_precision,
                              solver_tol=solver_tol, solver_maxiter=solver_maxiter,

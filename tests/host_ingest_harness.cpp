@@ -7,6 +7,7 @@
 //   * kl / ku are the band widths in caller order; every row's first entry has its largest column;
 //   * the chunk-of-8 rows hold the same entries, padded with (own row, 0, 0);
 //   * row blocks tile [0, N) in pieces of at most R rows; the LDS slot of every nonzero names its column;
+//   * the reverse Cuthill-McKee order of the band plan is a bijection and fh_bandwidth counts what it should;
 //   * malformed pointers / indices are rejected, never read out of bounds (the sanitizers watch).
 // Usage: host_ingest_harness [cases] [seed]   -> prints "ok <cases>" or aborts.
 #include <cassert>
@@ -160,6 +161,19 @@ static void one_case(std::mt19937_64& rng, bool real_chunks) {
                 else if (s != 0xFFFF) { CHECK(s >= R && s - R < P.ext_ptr[b + 1] - P.ext_ptr[b]); CHECK(P.ext_idx[P.ext_ptr[b] + (s - R)] == c); }
             }
         }
+    }
+    // band plan of the direct solver: reverse Cuthill-McKee gives a bijection, fh_bandwidth agrees with a direct count
+    {
+        std::vector<int> rperm;
+        fh_rcm(N, P.rowptr, P.col, rperm);
+        CHECK((int)rperm.size() == N);
+        std::vector<int> ip(N, -1);
+        for (int i = 0; i < N; ++i) { CHECK(rperm[i] >= 0 && rperm[i] < N && ip[rperm[i]] == -1); ip[rperm[i]] = i; }
+        int bkl = 0, bku = 0, ckl = 0, cku = 0;
+        fh_bandwidth(N, P.rowptr, P.col, ip.data(), bkl, bku);
+        for (int i = 0; i < N; ++i)
+            for (int k = P.rowptr[i]; k < P.rowptr[i + 1]; ++k) { ckl = std::max(ckl, ip[i] - ip[P.col[k]]); cku = std::max(cku, ip[P.col[k]] - ip[i]); }
+        CHECK(bkl == ckl && bku == cku && bkl < N && bku < N);
     }
     // malformed input is rejected: an index beyond N, a pointer beyond nnz, a pointer below the base
     if (!A.idx.empty()) {

@@ -85,16 +85,52 @@ def test_sparse_general_default_call_wide_pattern(engine):
     assert ri.info == 5 and ri.M == 0
 
 
-def test_sparse_general_default_call_large_maps_to_krylov(engine):
-    """Beyond the dense window the default maps to batched BiCGStab with the reference's iterative settings (zero guess,
-    rtol = atol = 10^-fpm[3], 500 iterations), recorded in stats and warned once.  N = 14 000 with the bulk of the
-    spectrum in a disc AWAY from the contour (centre 10, radius 2) and six eigenvalues inside it: z - A then has a
-    clustered spectrum off the origin plus six outliers and BiCGStab converges in a few dozen iterations."""
-    N = 14000
-    rng = np.random.default_rng(12)
+def _arrow_coupled_diag(delta, eps=1e-3):
+    """diag(delta) + a sparse superdiagonal + a full first row and column (a star graph: no renumbering gives it a band
+    narrower than N / 2), which a fill-reducing sparse LU factors without fill."""
+    N = len(delta)
+    j = np.arange(1, N)
+    rows = np.concatenate([np.arange(N), np.zeros(N - 1, dtype=int), j, np.arange(0, N - 1, 7)])
+    cols = np.concatenate([np.arange(N), j, np.zeros(N - 1, dtype=int), np.arange(1, N, 7)])
+    vals = np.concatenate([delta, np.full(N - 1, eps * (1 + 2j)), np.full(N - 1, -1.5j * eps), np.full(len(range(0, N - 1, 7)), 0.02)])
+    return sp.csr_matrix(sp.coo_matrix((vals, (rows, cols)), shape=(N, N)))
+
+
+def _clustered_spectrum(N, seed=12):
+    rng = np.random.default_rng(seed)
     delta = 10.0 + 2.0 * np.sqrt(rng.random(N)) * np.exp(2j * np.pi * rng.random(N))
-    delta[:6] = [0.3 + 0.1j, -0.2 + 0.4j, 0.5 - 0.3j, -0.4 - 0.2j, 0.1 + 0.6j, 0.0 - 0.5j]
-    A = _corner_coupled_diag(delta)
+    delta[1:7] = [0.3 + 0.1j, -0.2 + 0.4j, 0.5 - 0.3j, -0.4 - 0.2j, 0.1 + 0.6j, 0.0 - 0.5j]
+    return delta
+
+
+def test_sparse_general_default_call_large_maps_to_band_direct(engine):
+    """Beyond the dense window the default `solver=:direct` (UMFPACK in the reference) is served by the sparse direct solver
+    for general patterns whenever its factors fit the device: reverse Cuthill-McKee + blocked band LU.  The two far-corner
+    entries make the stored band N wide; the renumbering finds the narrow one."""
+    N = 14000
+    A = _corner_coupled_diag(_clustered_spectrum(N))
+    assert fk.api._sparse_direct_solver(A, None, 16) == "krylov"             # not a narrow band as stored, too large for dense
+    r = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine)
+    assert r.stats["solver_substitution"]["used"] == "band LU after reverse Cuthill-McKee"
+    assert r.info == 0 and r.M == 6 and r.stats["krylov_iterations"] == 0 and r.stats["factorizations"] == 16
+    kl, ku, nbytes, blocked = engine.band_plan()
+    assert kl + ku <= 64                    # (the ingest renumbering or the band plan's own: either way a narrow band again)
+    o = fo.feast_general(A, None, 0.0, 0.8, 6, ne=16)                     # sparse LU per node
+    assert o.info == 0 and o.M == 6
+    assert np.allclose(sorted(r.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-10)
+    assert r.loop == o.loop and r.epsout <= 1e-11
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0)
+    assert res.max() <= 1e-10
+
+
+def test_sparse_general_default_call_large_maps_to_krylov(engine):
+    """A pattern no renumbering can make a band of (a full row and column) at N = 14 000: beyond the dense window and the
+    band solver's reach, the default maps to batched BiCGStab with the reference's iterative settings (zero guess,
+    rtol = atol = 10^-fpm[3], 500 iterations), recorded in stats and warned once.  The bulk of the spectrum lies in a disc
+    AWAY from the contour (centre 10, radius 2) with six eigenvalues inside it: z - A then has a clustered spectrum off
+    the origin plus six outliers and BiCGStab converges in a few dozen iterations."""
+    N = 14000
+    A = _arrow_coupled_diag(_clustered_spectrum(N))
     assert fk.api._sparse_direct_solver(A, None, 16) == "krylov"
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")

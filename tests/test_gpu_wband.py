@@ -143,3 +143,25 @@ def test_sparse_direct_interior_interval_full_size():
     X = res.q[:, :res.M]
     R = A @ X - (B @ X) * res.lambda_[:res.M]
     assert (np.linalg.norm(R, axis=0) / np.maximum(np.abs(res.lambda_[:res.M]), 1.0)).max() <= 1e-10
+
+
+def test_default_call_falls_back_to_the_direct_solver(engine):
+    """`feast(A, B, interval)` with every keyword at its default, on an interval inside the spectrum: the Krylov sweeps the
+    default maps to (beyond the band / dense windows) stop with info = 5; solver=:direct was what the caller asked for, so
+    the call then runs the sparse direct solver and returns what the reference's default would have."""
+    A, B, lam = workloads.laplacian_3d_pencil(30, 24, 18)                 # N = 12 960: beyond the dense window
+    mid = 2.0
+    order = np.argsort(np.abs(lam - mid))
+    r = 0.5 * (abs(lam[order[19]] - mid) + abs(lam[order[20]] - mid))
+    inside = np.sort(lam[np.abs(lam - mid) < r])
+    assert inside.size == 20
+    assert fk.api._sparse_direct_solver(A, B, 8) == "krylov"
+    fpm = fk.feastinit(); fpm[4] = 4                                      # few refinement loops: the Krylov attempt ends quickly
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = fk.feast(A, B, (mid - r, mid + r), M0=32, fpm=fpm, engine=engine)
+    sub = res.stats["solver_substitution"]
+    assert sub["used"] == "cocg" and sub["fallback"].startswith("band LU") and sub["krylov_info"] == 5
+    assert res.info == 0 and res.M == 20
+    assert np.abs(np.sort(res.lambda_) - inside).max() <= 1e-10
