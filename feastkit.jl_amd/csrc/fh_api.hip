@@ -338,6 +338,21 @@ extern "C" int feasthip_set_csr(feasthip_handle h, int64_t N, int is_complex, in
     return set_csr_typed<double>(h, N, index_base, storage, nnzA, ptrA, idxA, (const double*)valA, nnzB, ptrB, idxB, (const double*)valB);
 }
 
+extern "C" int feasthip_release_factors(feasthip_handle h) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (h->side_stream) FH_CHECK(hipStreamSynchronize(h->side_stream));
+    for (void* p : h->lu_factors) if (p) hipFree(p);
+    for (int* p : h->lu_pivots) if (p) hipFree(p);
+    h->lu_factors.clear(); h->lu_pivots.clear(); h->lu_valid.clear(); h->lu_z.clear();
+    for (void* p : h->band_factors) if (p) hipFree(p);
+    for (int* p : h->band_pivots) if (p) hipFree(p);
+    h->band_factors.clear(); h->band_pivots.clear(); h->band_valid.clear(); h->band_z.clear();
+    return 0;
+}
+
 extern "C" int feasthip_band_plan(feasthip_handle h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
@@ -379,9 +394,9 @@ extern "C" int feasthip_set_contour(feasthip_handle h, int ne, const double* zne
     h->node_count = ne;
     h->node_ids.resize(ne);
     for (int e = 0; e < ne; ++e) h->node_ids[e] = e;
-    // cached factors belong to the old contour
-    for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
-    for (size_t i = 0; i < h->band_valid.size(); ++i) h->band_valid[i] = 0;
+    // cached factors stay: slot e is reused only when its shift equals the new z_e exactly (fh_dense_lu_solve_nodes,
+    // fh_banded_solve_nodes), so a repeated solve on the same contour keeps its factorisations and any other contour
+    // refactors slot by slot
     return 0;
 }
 
@@ -401,8 +416,6 @@ extern "C" int feasthip_set_node_range(feasthip_handle h, int first, int count) 
     h->node_count = count;
     h->node_ids.resize(count);
     for (int e = 0; e < count; ++e) h->node_ids[e] = first + e;
-    for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
-    for (size_t i = 0; i < h->band_valid.size(); ++i) h->band_valid[i] = 0;
     return 0;
 }
 
@@ -417,8 +430,6 @@ extern "C" int feasthip_set_node_list(feasthip_handle h, int count, const int* i
     h->node_ids.assign(indices, indices + count);
     h->node_first = count > 0 ? indices[0] : 0;
     h->node_count = count;
-    for (size_t i = 0; i < h->lu_valid.size(); ++i) h->lu_valid[i] = 0;
-    for (size_t i = 0; i < h->band_valid.size(); ++i) h->band_valid[i] = 0;
     return 0;
 }
 

@@ -1372,6 +1372,58 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_update(T* const* LUs, T* IN,
 // ---------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------
+// The side stream of the LU look-ahead (dense and band factorisations): created with a CU mask that leaves `reserve` CUs per
+// XCD to the main stream.  Returns false (and switches the look-ahead off for the handle) when no second stream can be had.
+static int lu_lookahead_reserve(int nf) { return getenv("FH_LU_RESERVE") ? atoi(getenv("FH_LU_RESERVE")) : std::min(4, (nf + 7) / 8); }
+static bool lu_side_stream(feasthip_ctx* h, int reserve) {
+    // CUs per XCD left to the main stream: one per panel workgroup the XCD receives (workgroups go round-robin over XCDs)
+    if (!h->side_stream || h->side_reserve != reserve) {
+        if (h->side_stream) {
+            if (hipStreamSynchronize(h->side_stream) != hipSuccess) return false;
+            (void)hipStreamDestroy(h->side_stream);
+            h->side_stream = nullptr;
+        }
+        // A panel workgroup (1024 threads x 128 VGPRs) needs a completely empty CU, and the rest update refills every CU
+        // as soon as a tile retires, so on a plain (even low-priority) side stream the panels starved until the tail of
+        // the update (measured: 676 ms of panel time instead of 123).  The side stream is therefore created with a CU mask
+        // that leaves `reserve` CUs per XCD to the main stream.  The reserved set {i : i mod 32 == (i / 32) mod 8 + 8 m,
+        // m < reserve} has `reserve` members in every XCD both for an interleaved (XCD = i mod 8, what the kernel driver
+        // uses on multi-XCD parts) and a blocked (XCD = i / 32) numbering of the mask bits.
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; ++i) {
+            bool reserved = false;
+            for (int m = 0; m < reserve; ++m) reserved |= (i % 32) == ((i / 32) % 8 + 8 * m);
+            if (!reserved) mask[i / 32] |= 1u << (i % 32);
+        }
+        // a runtime without CU masks (or a partition mode that refuses them) falls back to the plain low-priority stream,
+        // and without any second stream to the serial order: the look-ahead is an optimisation, never a reason to fail
+        bool have = reserve > 0 && hipExtStreamCreateWithCUMask(&h->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+        if (!have) {
+            (void)hipGetLastError();
+            h->side_stream = nullptr;
+            int prio_lo = 0, prio_hi = 0;
+            have = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess &&
+                   hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
+        }
+        if (have && !h->lu_ev_next)
+            have = hipEventCreateWithFlags(&h->lu_ev_next, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&h->lu_ev_rest, hipEventDisableTiming) == hipSuccess;
+        if (!have) {
+            (void)hipGetLastError();
+            if (h->side_stream) { (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
+            h->lu_lookahead = 0;
+            return false;
+        }
+        h->side_reserve = reserve;
+    }
+    return true;
+}
+
 template <typename T>
 static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const std::vector<cplx>& zlist,
                            std::vector<int>& info_out) {
@@ -1465,51 +1517,8 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     bool lookahead = h->lu_lookahead != 0 && N > 2 * KB;
     const hipStream_t main_s = h->stream;
     // CUs per XCD left to the main stream: one per panel workgroup the XCD receives (workgroups go round-robin over XCDs)
-    const int reserve = getenv("FH_LU_RESERVE") ? atoi(getenv("FH_LU_RESERVE")) : std::min(4, (nf + 7) / 8);
-    if (lookahead && (!h->side_stream || h->side_reserve != reserve)) {
-        if (h->side_stream) {
-            FH_CHECK(hipStreamSynchronize(h->side_stream));
-            FH_CHECK(hipStreamDestroy(h->side_stream));
-            h->side_stream = nullptr;
-        }
-        // A panel workgroup (1024 threads x 128 VGPRs) needs a completely empty CU, and the rest update refills every CU
-        // as soon as a tile retires, so on a plain (even low-priority) side stream the panels starved until the tail of
-        // the update (measured: 676 ms of panel time instead of 123).  The side stream is therefore created with a CU mask
-        // that leaves `reserve` CUs per XCD to the main stream.  The reserved set {i : i mod 32 == (i / 32) mod 8 + 8 m,
-        // m < reserve} has `reserve` members in every XCD both for an interleaved (XCD = i mod 8, what the kernel driver
-        // uses on multi-XCD parts) and a blocked (XCD = i / 32) numbering of the mask bits.
-        hipDeviceProp_t prop;
-        int dev = 0;
-        FH_CHECK(hipGetDevice(&dev));
-        FH_CHECK(hipGetDeviceProperties(&prop, dev));
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 0; i < ncu; ++i) {
-            bool reserved = false;
-            for (int m = 0; m < reserve; ++m) reserved |= (i % 32) == ((i / 32) % 8 + 8 * m);
-            if (!reserved) mask[i / 32] |= 1u << (i % 32);
-        }
-        // a runtime without CU masks (or a partition mode that refuses them) falls back to the plain low-priority stream,
-        // and without any second stream to the serial order: the look-ahead is an optimisation, never a reason to fail
-        bool have = reserve > 0 && hipExtStreamCreateWithCUMask(&h->side_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-        if (!have) {
-            (void)hipGetLastError();
-            h->side_stream = nullptr;
-            int prio_lo = 0, prio_hi = 0;
-            have = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess &&
-                   hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
-        }
-        if (have && !h->lu_ev_next)
-            have = hipEventCreateWithFlags(&h->lu_ev_next, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&h->lu_ev_rest, hipEventDisableTiming) == hipSuccess;
-        if (!have) {
-            (void)hipGetLastError();
-            if (h->side_stream) { (void)hipStreamDestroy(h->side_stream); h->side_stream = nullptr; }
-            h->lu_lookahead = 0;
-            lookahead = false;
-        }
-        h->side_reserve = reserve;
-    }
+    const int reserve = lu_lookahead_reserve(nf);
+    if (lookahead && !lu_side_stream(h, reserve)) lookahead = false;
     // measured (cfg 2 sweeps): no look-ahead 84 ms, plain side stream 79, plain + 4 chunks 74, CU mask 68, mask + chunks 72
     const int lu_chunks = getenv("FH_LU_CHUNKS") ? std::max(1, atoi(getenv("FH_LU_CHUNKS"))) : (reserve > 0 ? 1 : KB / LU_NB);
     bool rest_pending = false;
@@ -1912,6 +1921,16 @@ int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbase
         if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
         else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
     };
+    // Look-ahead, as in the dense factorisation: the panels of a block column run one workgroup per node, so the update right
+    // of block column b is split by columns -- the NEXT block column [Kend, Kend + WB) on the main stream, the REST
+    // [Kend + WB, nc) on the CU-masked side stream -- and the panels of block column b+1 overlap the rest.  The rest reads the
+    // L columns and pivots of block b and writes only columns >= Kend + WB; block column b+1 writes only its own columns and
+    // pivots until it waits for the rest (its interchanges to the right touch the same columns).  No interchanges go to the
+    // left in the band factorisation, so nothing else is shared.  Same operations on every element: identical factors.
+    bool lookahead = h->lu_lookahead != 0 && kl + ku > 2 * WB && N > 4 * WB;
+    if (lookahead && !lu_side_stream(h, lu_lookahead_reserve(nf))) lookahead = false;
+    const hipStream_t main_s = h->stream;
+    bool rest_pending = false;
     for (int K0 = 0; K0 < N; K0 += WB) {
         const int Kend = std::min(N, K0 + WB);
         const int nr = std::min(N, Kend + kl);                 // rows the block column reaches
@@ -1931,14 +1950,36 @@ int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbase
                 gemm(k0, LU_NB, k0 + nb, nr, k0 + nb, Kend);
             }
         }
-        if (Kend >= N) break;
-        laswp(K0, Kend - K0, 0, 0, Kend, nc);                  // to the right; never to the left (ZGBTRF)
-        for (int k0 = K0; k0 < Kend; k0 += LU_NB) {            // Kend - K0 == WB here
-            trsm(k0, LU_NB, Kend, nc);
-            gemm(k0, LU_NB, k0 + LU_NB, Kend, Kend, nc);
+        if (rest_pending) {
+            if (hipStreamWaitEvent(main_s, h->lu_ev_rest, 0) != hipSuccess) { h->stream = main_s; h->last_error = "hipStreamWaitEvent(band LU)"; return FEASTHIP_ERROR_INTERNAL; }
+            rest_pending = false;
         }
-        gemm(K0, WB, Kend, nr, Kend, nc);
+        if (Kend >= N) break;
+        // interchanges (to the right only: ZGBTRF), U block row and update of the columns [a, b) right of the block column
+        auto right_of_block = [&](int a, int b) {
+            if (a >= b) return;
+            laswp(K0, Kend - K0, 0, 0, a, b);
+            for (int k0 = K0; k0 < Kend; k0 += LU_NB) {        // Kend - K0 == WB here
+                trsm(k0, LU_NB, a, b);
+                gemm(k0, LU_NB, k0 + LU_NB, Kend, a, b);
+            }
+            gemm(K0, WB, Kend, nr, a, b);
+        };
+        const int Kend2 = lookahead ? std::min(nc, Kend + WB) : nc;
+        right_of_block(Kend, Kend2);
+        if (Kend2 < nc) {
+            hipError_t er = hipEventRecord(h->lu_ev_next, main_s);
+            if (er == hipSuccess) er = hipStreamWaitEvent(h->side_stream, h->lu_ev_next, 0);
+            if (er != hipSuccess) { h->last_error = "hipEventRecord(band LU)"; return FEASTHIP_ERROR_INTERNAL; }
+            h->stream = h->side_stream;                        // the launch helpers follow h->stream
+            right_of_block(Kend2, nc);
+            er = hipEventRecord(h->lu_ev_rest, h->side_stream);
+            h->stream = main_s;
+            if (er != hipSuccess) { h->last_error = "hipEventRecord(band LU)"; return FEASTHIP_ERROR_INTERNAL; }
+            rest_pending = true;
+        }
     }
+    if (rest_pending && hipStreamWaitEvent(main_s, h->lu_ev_rest, 0) != hipSuccess) { h->last_error = "hipStreamWaitEvent(band LU)"; return FEASTHIP_ERROR_INTERNAL; }
     hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dbases, geom);
     {
         dim3 g(SOLVE_KB / 16, (N + SOLVE_KB - 1) / SOLVE_KB, nf);

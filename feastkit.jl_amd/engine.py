@@ -363,6 +363,10 @@ class HipEngine:
         self.last_stats = stats.asdict()
         return dY, rc
 
+    def free_factors(self):
+        """Drop the cached LU / band factors of the direct solvers (feasthip_release_factors)."""
+        self._chk(self.lib.feasthip_release_factors(self.h))
+
     def band_plan(self):
         """(kl, ku, bytes per node, blocked) of the band the direct sparse solver would eliminate (feasthip_band_plan)."""
         kl, ku, blocked = C.c_int(0), C.c_int(0), C.c_int(0)

@@ -194,6 +194,11 @@ int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
  * BiCGStab/COCG: correction solve on complex64 panels around an fp64 residual (inexact-solve mode).
  * cache_factors: keep LU factors per
  * node across calls (src/dense/feast_dense.jl:147,188).                                 */
+/* Free the cached factorisations of the direct solvers (dense LU, band LU): the reference keeps `lu(z B - A)` per node for
+ * the life of a driver call (factor cache, src/dense/feast_dense.jl:458, 487-497) and the garbage collector takes them;
+ * here they live until the problem changes, the handle is destroyed, or this call.  The next direct solve factors again.  */
+int  feasthip_release_factors(feasthip_handle h);
+
 /* The band FEASTHIP_SOLVER_BANDED would eliminate for the current CSR problem (after its reordering) and the device memory
  * of ONE node's factor; *blocked = 1 when the blocked band LU on the dense kernels is used.  A host shim uses it to decide
  * between the direct and the iterative solvers (the reference decides by keyword only: src/sparse/feast_sparse.jl:249-252).
