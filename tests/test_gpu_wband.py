@@ -165,3 +165,26 @@ def test_default_call_falls_back_to_the_direct_solver(engine):
     assert sub["used"] == "cocg" and sub["fallback"].startswith("band LU") and sub["krylov_info"] == 5
     assert res.info == 0 and res.M == 20
     assert np.abs(np.sort(res.lambda_) - inside).max() <= 1e-10
+
+
+def test_blocked_band_fuzz(engine, force_blocked):
+    """Seeded random shapes through the blocked band LU: size, band, fill, right-hand sides, value type, pattern symmetry,
+    B present or not -- every case against SuperLU."""
+    rng = np.random.default_rng(20260515)
+    for case in range(14):
+        n = int(rng.integers(140, 2600))
+        band = int(rng.integers(3, min(420, n // 3)))
+        density = float(rng.uniform(0.02, 0.6)) * min(1.0, 40.0 / band)
+        m = int(rng.integers(1, 65))
+        cplx = bool(rng.integers(0, 2))
+        sym = bool(rng.integers(0, 2))
+        A, B = random_pencil(n, band, density, 1000 + case, cplx, sym)
+        if rng.integers(0, 3) == 0:
+            B = None
+        engine.set_problem(A, B)
+        engine.set_solver("banded")
+        z = complex(rng.uniform(-0.5, 0.5), rng.uniform(0.05, 1.0))
+        try:
+            check_solve(engine, A, B, z, m, seed=case)
+        except AssertionError as exc:
+            raise AssertionError(f"case {case}: n={n} band={band} density={density:.3f} m={m} cplx={cplx} sym={sym} B={'I' if B is None else 'tri'}: {exc}")
