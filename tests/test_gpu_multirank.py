@@ -37,6 +37,13 @@ Ag = np.diag([0.5+0.1j, 1.0+0.2j, 2.0-0.1j, 4.0]) + 0.01 * np.triu(np.ones((4, 4
 eng = fk.HipEngine(0)
 g = fk.feast_hip_general(eng, Ag, None, 1.0+0.1j, 1.3, 4, fk.feastinit())
 out += [g.info, g.M] + list(np.sort(g.lambda_.real))
+# sparse direct solver (blocked band LU after reverse Cuthill-McKee), 8 nodes over 2 ranks: each rank factors its own 4
+os.environ["FH_WBAND"] = "1"
+eng = fk.HipEngine(0)
+fpm = fk.feastinit(); fpm[2] = 8
+d = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 32, fpm, solver="banded")
+out += [d.info, d.M, d.epsout, d.stats.get("factorizations", -1)] + list(np.sort(d.lambda_))
+eng.close()
 np.save(r"{out}/g%d.npy" % rank, np.array(out, dtype=float))
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -66,6 +73,9 @@ def test_two_ranks_one_gpu_match_single_rank(engine, tmp_path):
         assert np.allclose(g0[off + 3: off + 3 + n], np.sort(one.lambda_), atol=1e-10)
     off = 3 * (3 + n)
     assert (int(g0[off]), int(g0[off + 1])) == (0, 3) and np.allclose(g0[off + 2: off + 5], [0.5, 1.0, 2.0], atol=1e-8)
+    off += 5
+    assert (int(g0[off]), int(g0[off + 1])) == (0, n) and g0[off + 2] <= 1e-12 and int(g0[off + 3]) == 4     # 4 of the 8 nodes factored per rank
+    assert np.allclose(g0[off + 4: off + 4 + n], inside, atol=1e-10)
 
 
 WORKER4 = r'''
