@@ -1033,11 +1033,16 @@ static bool fh_is_complex_input(feasthip_ctx* h) { return h->kind == 2 ? h->csr.
 // The residual is the fp64 dense operator kernel, so the result has fp64 accuracy as long as
 // cond(z_e B - A) * eps32 < 1.  `single`: one shift through fh_dense_lu_solve_single (nodes == 1).
 static int fh_dense_lu_refined(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* Rhs, cplx* Y,
-                               size_t panel, std::vector<int>& status, int64_t* nfact, bool single, double* worst_out) {
+                               size_t panel, std::vector<int>& status, int64_t* nfact, bool single, double* worst_out, bool banded = false) {
     const int N = (int)fh_N(h);
     int rc;
     void* p;
+    // banded: the same loop over the complex64 band factors of the sparse direct solver (residual = fp64 SpMM)
     auto solve = [&](const cplx* rhs, size_t rhs_stride, cplx* out, int64_t* nf) -> int {
+        if (banded) {
+            if (single) return fh_banded_solve_single(h, ld, m, z[0], rhs, out, &status[0], nf);
+            return fh_banded_solve_nodes(h, ld, m, nodes, z, rhs, rhs_stride, out, panel, status, nf);
+        }
         if (single) return fh_dense_lu_solve_single(h, ld, m, z[0], rhs, out, &status[0], nf);
         return fh_dense_lu_solve_nodes(h, ld, m, nodes, z, rhs, rhs_stride, out, panel, status, nf);
     };
@@ -1169,9 +1174,11 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         int64_t nfact = 0;
-        rc = fh_banded_solve_nodes(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact);
+        double worst = 0.0;
+        if (h->factor_precision == 32) rc = fh_dense_lu_refined(h, ld, m, nodes, z, Rhs, Y, panel, status, &nfact, false, &worst, true);
+        else rc = fh_banded_solve_nodes(h, ld, m, nodes, z, Rhs, 0, Y, panel, status, &nfact);
         if (rc) return rc;
-        if (stats) stats->factorizations = nfact;
+        if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB || h->solver == FEASTHIP_SOLVER_COCG) {
         if (h->solver == FEASTHIP_SOLVER_COCG && fh_is_complex_input(h)) {
             h->last_error = "solver COCG needs a complex-SYMMETRIC shifted matrix: real-symmetric A and B only";
@@ -2437,9 +2444,11 @@ extern "C" int feasthip_shifted_solve_dev(feasthip_handle h, double z_re, double
         if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BANDED) {
         int64_t nfact = 0;
-        rc = fh_banded_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
+        double worst = 0.0;
+        if (h->factor_precision == 32) rc = fh_dense_lu_refined(h, ld, m, 1, z, Rhs, Y, panel, status, &nfact, true, &worst, true);
+        else rc = fh_banded_solve_single(h, ld, m, z[0], Rhs, Y, &status[0], &nfact);
         if (rc) return rc;
-        if (stats) stats->factorizations = nfact;
+        if (stats) { stats->factorizations = nfact; stats->max_rel_residual = worst; }
     } else if (h->solver == FEASTHIP_SOLVER_BICGSTAB || h->solver == FEASTHIP_SOLVER_COCG) {
         if (h->solver == FEASTHIP_SOLVER_COCG && fh_is_complex_input(h)) {
             h->last_error = "solver COCG needs real-symmetric A and B";

@@ -117,10 +117,11 @@ __global__ __launch_bounds__(BAND_THREADS) void k_band_lu(cplx* const* ABs, int*
 }
 
 // Y[node] = RHS (shared right-hand side panel, row-major N x ld)
-__global__ __launch_bounds__(FH_BLOCK) void k_band_copy_rhs(const cplx* __restrict__ RHS, cplx* __restrict__ Y, size_t stride,
+__global__ __launch_bounds__(FH_BLOCK) void k_band_copy_rhs(const cplx* __restrict__ RHS, size_t rhs_stride, cplx* __restrict__ Y, size_t stride,
                                                              size_t total) {
     cplx* Yn = Y + (size_t)blockIdx.y * stride;
-    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) Yn[e] = RHS[e];
+    const cplx* Rn = RHS + (size_t)blockIdx.y * rhs_stride;     // rhs_stride = 0: one right-hand side panel shared by all nodes
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) Yn[e] = Rn[e];
 }
 
 // ZGBTRS on a row-major N x ld panel: one workgroup per (16-column tile, node); thread = (row lane, column)
@@ -221,7 +222,7 @@ static int band_make_plan(feasthip_ctx* h) {
 
 static size_t band_slot_bytes(feasthip_ctx* h) {
     const size_t N = (size_t)h->csr.N;
-    if (h->band_plan == 2) return fh_wband_elems((int)N, h->band_kl, h->band_ku) * sizeof(cplx);
+    if (h->band_plan == 2) return fh_wband_elems((int)N, h->band_kl, h->band_ku) * (h->band_prec == 32 ? sizeof(cplxf) : sizeof(cplx));
     return ((size_t)2 * h->band_kl + h->band_ku + 1) * N * sizeof(cplx);
 }
 
@@ -240,6 +241,14 @@ static int band_check(feasthip_ctx* h) {
 
 static int band_ensure_slots(feasthip_ctx* h, int nslots) {
     const size_t N = (size_t)h->csr.N;
+    // complex64 factors (feasthip_set_solver factor_precision = 32) exist for the blocked plan only; the caller refines in fp64
+    const int prec = (h->band_plan == 2 && h->factor_precision == 32) ? 32 : 64;
+    if (prec != h->band_prec) {
+        for (void* p : h->band_factors) if (p) hipFree(p);
+        for (int* p : h->band_pivots) if (p) hipFree(p);
+        h->band_factors.clear(); h->band_pivots.clear(); h->band_valid.clear(); h->band_z.clear();
+        h->band_prec = prec;
+    }
     const size_t bytes = band_slot_bytes(h);
     const int missing = nslots - (int)h->band_factors.size();
     if (missing > 0) {
@@ -267,7 +276,8 @@ static int band_pointer_arrays(feasthip_ctx* h, const std::vector<int>& which, c
     int rc;
     std::vector<cplx*> abs(nf);
     std::vector<int*> pvs(nf), perms(nf, h->band_perm);
-    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)h->band_factors[which[q]] + off; pvs[q] = h->band_pivots[which[q]]; }
+    const size_t esz = (h->band_plan == 2 && h->band_prec == 32) ? sizeof(cplxf) : sizeof(cplx);
+    for (int q = 0; q < nf; ++q) { abs[q] = (cplx*)((char*)h->band_factors[which[q]] + off * esz); pvs[q] = h->band_pivots[which[q]]; }
     if ((rc = fh_get_buf(h, "bd_ptrs", nf * sizeof(cplx*), &p))) return rc;
     cplx** dabs = (cplx**)p;
     if ((rc = fh_get_buf(h, "bd_pptrs", nf * sizeof(int*), &p))) return rc;
@@ -298,9 +308,9 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
     FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemsetAsync(dinfo, 0, nf * sizeof(int), h->stream));
     if (h->band_plan == 2) {
-        std::vector<cplx*> abs(nf);
-        for (int q = 0; q < nf; ++q) abs[q] = (cplx*)h->band_factors[which[q]];
-        if ((rc = fh_wband_factor(h, nf, abs.data(), dabs, dpvs, dz, dinfo, h->band_iperm, kl, ku))) return rc;
+        std::vector<void*> abs(nf);
+        for (int q = 0; q < nf; ++q) abs[q] = h->band_factors[which[q]];
+        if ((rc = fh_wband_factor(h, h->band_prec, nf, abs.data(), (void**)dabs, dpvs, dz, dinfo, h->band_iperm, kl, ku))) return rc;
     } else {
         const size_t ldab = (size_t)2 * kl + ku + 1;
         for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(h->band_factors[which[q]], 0, ldab * N * sizeof(cplx), h->stream));
@@ -324,7 +334,7 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
     return 0;
 }
 
-static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<int>& slots, const cplx* RHS, cplx* Y, size_t stride) {
+static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<int>& slots, const cplx* RHS, size_t rhs_stride, cplx* Y, size_t stride) {
     const int nf = (int)slots.size();
     const int N = (int)h->csr.N;
     int rc;
@@ -333,21 +343,22 @@ static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<in
     if (h->band_plan == 2) {
         void* p;
         const size_t bstride = (size_t)N * ld;
-        if ((rc = fh_get_buf(h, "bd_ypanel", (size_t)nf * bstride * sizeof(cplx), &p))) return rc;
-        cplx* Yb = (cplx*)p;
-        if ((rc = fh_get_buf(h, "bd_zpanel", (size_t)nf * bstride * sizeof(cplx), &p))) return rc;
-        cplx* Zb = (cplx*)p;
-        return fh_wband_solve(h, nf, dabs, dpvs, dperms, h->band_perm, RHS, Y, stride, Yb, Zb, ld, m, h->band_kl, h->band_ku);
+        const size_t esz = h->band_prec == 32 ? sizeof(cplxf) : sizeof(cplx);
+        if ((rc = fh_get_buf(h, "bd_ypanel", (size_t)nf * bstride * esz, &p))) return rc;
+        void* Yb = p;
+        if ((rc = fh_get_buf(h, "bd_zpanel", (size_t)nf * bstride * esz, &p))) return rc;
+        void* Zb = p;
+        return fh_wband_solve(h, h->band_prec, nf, (void**)dabs, dpvs, dperms, h->band_perm, RHS, rhs_stride, Y, stride, Yb, Zb, ld, m, h->band_kl, h->band_ku);
     }
     fh_prof_begin(h, "band_solve");
     const size_t total = (size_t)N * ld;
-    hipLaunchKernelGGL(k_band_copy_rhs, dim3((unsigned)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048), nf), dim3(FH_BLOCK), 0, h->stream, RHS, Y, stride, total);
+    hipLaunchKernelGGL(k_band_copy_rhs, dim3((unsigned)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048), nf), dim3(FH_BLOCK), 0, h->stream, RHS, rhs_stride, Y, stride, total);
     hipLaunchKernelGGL(k_band_solve, dim3(ld / 16, nf), dim3(FH_BLOCK), 0, h->stream, dabs, dpvs, Y, stride, N, ld, h->band_kl, h->band_ku);
     fh_prof_end(h);
     return 0;
 }
 
-int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, cplx* Y,
+int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::vector<cplx>& z, const cplx* RHS, size_t rhs_stride, cplx* Y,
                           size_t stride, std::vector<int>& status, int64_t* nfact) {
     int rc = band_check(h);
     if (rc) return rc;
@@ -367,7 +378,7 @@ int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::
     if (nfact) *nfact = (int64_t)need.size();
     std::vector<int> slots(nodes);
     for (int e = 0; e < nodes; ++e) slots[e] = e;
-    if ((rc = band_solve_batch(h, ld, m, slots, RHS, Y, stride))) return rc;
+    if ((rc = band_solve_batch(h, ld, m, slots, RHS, rhs_stride, Y, stride))) return rc;
     status.assign(nodes, 0);
     for (int e = 0; e < nodes; ++e) if (h->band_valid[e] != 1) status[e] = FEASTHIP_ERROR_LAPACK;
     return 0;
@@ -391,7 +402,7 @@ int fh_banded_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* R
         h->band_valid[slot] = info[0] == 0 ? 1 : -1;
         if (nfact) *nfact = 1;
     }
-    if ((rc = band_solve_batch(h, ld, m, need, RHS, Y, (size_t)h->csr.N * ld))) return rc;
+    if ((rc = band_solve_batch(h, ld, m, need, RHS, 0, Y, (size_t)h->csr.N * ld))) return rc;
     *status = h->band_valid[slot] == 1 ? 0 : FEASTHIP_ERROR_LAPACK;
     return 0;
 }

@@ -175,6 +175,7 @@ struct feasthip_ctx {
     // band plan (fh_banded.hip): 0 not made, 1 narrow band in stored order (one-workgroup elimination), 2 blocked band LU
     // on the dense kernels in band order (band_perm[band row] = stored row, band_iperm its inverse; both on the device)
     int band_plan = 0, band_kl = 0, band_ku = 0;
+    int band_prec = 64;           // element type of the cached band factors (blocked plan): 64 = complex128, 32 = complex64
     int* band_perm = nullptr;
     int* band_iperm = nullptr;
     std::vector<void*> band_factors;

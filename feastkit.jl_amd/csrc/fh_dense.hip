@@ -1795,27 +1795,27 @@ size_t fh_wband_elems(int N, int kl, int ku) { return wband_geometry(N, kl, ku).
 size_t fh_wband_base_offset(int N, int kl, int ku) { return (size_t)wband_geometry(N, kl, ku).kvp; }
 
 // base[i' + j' ld] = z B - A for the renumbered unknowns i' = iperm[i] (iperm null: as stored); the storage was zeroed
-template <typename VT, bool BIDENT>
+template <typename VT, bool BIDENT, typename T>
 __global__ __launch_bounds__(FH_BLOCK) void k_wband_form(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                           const VT* __restrict__ aval, const VT* __restrict__ bval,
-                                                          cplx* const* bases, const cplx* z, const int* __restrict__ iperm, int N, int ld) {
-    cplx* base = bases[blockIdx.y];
+                                                          T* const* bases, const cplx* z, const int* __restrict__ iperm, int N, int ld) {
+    T* base = bases[blockIdx.y];
     const cplx zz = z[blockIdx.y];
     const int i = blockIdx.x * FH_BLOCK + threadIdx.x;
     if (i >= N) return;
     const int bi = iperm ? iperm[i] : i;
-    if (BIDENT) base[(size_t)bi * ld + bi] = zz;
+    if (BIDENT) base[(size_t)bi * ld + bi] = cvt<T>(zz);
     for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
         const int bj = iperm ? iperm[col[k]] : col[k];
         cplx a;
         if constexpr (sizeof(VT) == sizeof(cplx)) a = cmake(aval[k].x, aval[k].y); else a = cmake(aval[k], 0.0);
-        cplx* dst = base + (size_t)bj * ld + bi;
+        T* dst = base + (size_t)bj * ld + bi;
         if (BIDENT) {
-            *dst = csub(*dst, a);
+            *dst = cvt<T>(csub(to_d(*dst), a));
         } else {
             cplx b;
             if constexpr (sizeof(VT) == sizeof(cplx)) b = cmake(bval[k].x, bval[k].y); else b = cmake(bval[k], 0.0);
-            *dst = csub(cmul(zz, b), a);
+            *dst = cvt<T>(csub(cmul(zz, b), a));
         }
     }
 }
@@ -1823,12 +1823,13 @@ __global__ __launch_bounds__(FH_BLOCK) void k_wband_form(const int* __restrict__
 // The row interchanges piv[K0 .. K0 + nbk) of one block column applied to the rows [K0, K0 + W) of row-major panels:
 // the swaps are composed on row INDICES in LDS (one thread, nbk short steps), the (at most 2 nbk) rows that end up
 // somewhere else are read by all threads into registers and written to their places.  grid (ld / 16, nodes).
-__global__ __launch_bounds__(FH_BLOCK) void k_wband_swap(int* const* pivs, cplx* Y, size_t stride, int ld, int K0, int nbk, int W) {
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_wband_swap(int* const* pivs, T* Y, size_t stride, int ld, int K0, int nbk, int W) {
     extern __shared__ int wb_cur[];          // [W] original row (relative to K0) now at position i
     __shared__ int s_dst[2 * WB], s_src[2 * WB];
     __shared__ int s_cnt;
     const int* piv = pivs[blockIdx.y] + K0;
-    cplx* Yn = Y + (size_t)blockIdx.y * stride + 16 * blockIdx.x;
+    T* Yn = Y + (size_t)blockIdx.y * stride + 16 * blockIdx.x;
     const int t = threadIdx.x;
     for (int i = t; i < W; i += FH_BLOCK) wb_cur[i] = i;
     if (t == 0) s_cnt = 0;
@@ -1847,11 +1848,11 @@ __global__ __launch_bounds__(FH_BLOCK) void k_wband_swap(int* const* pivs, cplx*
     const int cnt = min(s_cnt, 2 * WB);
     const int c = t & 15, rr = t >> 4;
     constexpr int RL = FH_BLOCK / 16, NV = 2 * WB / RL;
-    cplx v[NV];
+    T v[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         const int e = rr + q * RL;
-        v[q] = e < cnt ? Yn[(size_t)(K0 + s_src[e]) * ld + c] : cmake(0, 0);
+        v[q] = e < cnt ? Yn[(size_t)(K0 + s_src[e]) * ld + c] : LU_MK(0, 0);
     }
     __syncthreads();
 #pragma unroll
@@ -1862,38 +1863,39 @@ __global__ __launch_bounds__(FH_BLOCK) void k_wband_swap(int* const* pivs, cplx*
 }
 
 // Y[node][perm[i], :] = Yb[node][i, :]
-__global__ __launch_bounds__(FH_BLOCK) void k_scatter_rows(const cplx* __restrict__ Yb, size_t bstride, const int* __restrict__ perm,
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_scatter_rows(const T* __restrict__ Yb, size_t bstride, const int* __restrict__ perm,
                                                             cplx* __restrict__ Y, size_t stride, int N, int ld) {
-    const cplx* s = Yb + (size_t)blockIdx.y * bstride;
+    const T* s = Yb + (size_t)blockIdx.y * bstride;
     cplx* d = Y + (size_t)blockIdx.y * stride;
     const size_t total = (size_t)N * ld;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         const size_t i = e / ld, c = e % ld;
-        d[(size_t)(perm ? perm[i] : (int)i) * ld + c] = s[e];
+        d[(size_t)(perm ? perm[i] : (int)i) * ld + c] = to_d(s[e]);
     }
 }
 
 // Form z B - A in band storage (zeroed here) and factor it, nf nodes at once.  dabs: device array of the nf storage pointers
 // (AB, not base), dbases: the same plus kvp; dpvs: pivots (N ints per node, global row indices); info_out[q] = 0 or the
 // 1-based column of a zero pivot.
-int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbases, int** dpvs, const cplx* dz, int* dinfo,
-                    const int* d_iperm, int kl, int ku) {
-    typedef cplx T;
+template <typename T>
+static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** dbases, int** dpvs, const cplx* dz, int* dinfo,
+                          const int* d_iperm, int kl, int ku) {
     const int N = (int)h->csr.N;
     const wband_geom w = wband_geometry(N, kl, ku);
     const lu_geom geom = w.g;
     const int lda = geom.ld;
     fh_prof_begin(h, "wband_form");
-    for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(abs_host[q], 0, (size_t)w.ldab * N * sizeof(cplx), h->stream));
+    for (int q = 0; q < nf; ++q) FH_CHECK(hipMemsetAsync(abs_host[q], 0, (size_t)w.ldab * N * sizeof(T), h->stream));
     {
         const dim3 grid((N + FH_BLOCK - 1) / FH_BLOCK, nf), block(FH_BLOCK);
         const bool bid = h->csr.b_identity != 0;
         if (h->csr.is_complex) {
-            if (bid) hipLaunchKernelGGL((k_wband_form<cplx, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)nullptr, dbases, dz, d_iperm, N, lda);
-            else hipLaunchKernelGGL((k_wband_form<cplx, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dbases, dz, d_iperm, N, lda);
+            if (bid) hipLaunchKernelGGL((k_wband_form<cplx, true, T>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)nullptr, dbases, dz, d_iperm, N, lda);
+            else hipLaunchKernelGGL((k_wband_form<cplx, false, T>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dbases, dz, d_iperm, N, lda);
         } else {
-            if (bid) hipLaunchKernelGGL((k_wband_form<double, true>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)nullptr, dbases, dz, d_iperm, N, lda);
-            else hipLaunchKernelGGL((k_wband_form<double, false>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)h->csr.bval, dbases, dz, d_iperm, N, lda);
+            if (bid) hipLaunchKernelGGL((k_wband_form<double, true, T>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)nullptr, dbases, dz, d_iperm, N, lda);
+            else hipLaunchKernelGGL((k_wband_form<double, false, T>), grid, block, 0, h->stream, h->csr.rowptr, h->csr.col, (const double*)h->csr.aval, (const double*)h->csr.bval, dbases, dz, d_iperm, N, lda);
         }
     }
     fh_prof_end(h);
@@ -1918,7 +1920,8 @@ int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbase
         const int sw = std::min(8, TC);
         const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
         const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nf);
-        if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
+        if constexpr (sizeof(T) != sizeof(cplx)) hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
+        else if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
         else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
     };
     // Look-ahead, as in the dense factorisation: the panels of a block column run one workgroup per node, so the update right
@@ -1991,9 +1994,8 @@ int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbase
     return 0;
 }
 
-template <int LD>
-static void wband_solve_launch(feasthip_ctx* h, cplx** dbases, int** dpvs, cplx* Y, cplx* Z, size_t stride, const wband_geom& w, int nf, int m) {
-    typedef cplx T;
+template <int LD, typename T>
+static void wband_solve_launch(feasthip_ctx* h, T** dbases, int** dpvs, T* Y, T* Z, size_t stride, const wband_geom& w, int nf, int m) {
     const int N = w.N, kl = w.kl, kv = w.kl + w.ku;
     const lu_geom geom = w.g;
     const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
@@ -2002,7 +2004,7 @@ static void wband_solve_launch(feasthip_ctx* h, cplx** dbases, int** dpvs, cplx*
         const int K0 = b * SOLVE_KB, Kend = std::min(N, K0 + SOLVE_KB);
         const int kb = (Kend - K0 + LU_NB - 1) / LU_NB;
         const int nr = std::min(N, Kend + kl);
-        hipLaunchKernelGGL(k_wband_swap, dim3(LD / 16, nf), dim3(FH_BLOCK), (size_t)(nr - K0) * sizeof(int), h->stream, dpvs, Y, stride, LD, K0, Kend - K0, nr - K0);
+        hipLaunchKernelGGL((k_wband_swap<T>), dim3(LD / 16, nf), dim3(FH_BLOCK), (size_t)(nr - K0) * sizeof(int), h->stream, dpvs, Y, stride, LD, K0, Kend - K0, nr - K0);
         hipLaunchKernelGGL((k_solve_diag_inv<LD, false, T>), dim3(cta, nf), dim3(FH_BLOCK), 0, h->stream, dbases, Y, Z, stride, geom, K0, kb);
         if (Kend < nr)
             hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((nr - Kend + 63) / 64, nf), dim3(FH_BLOCK), 0, h->stream, dbases, Y, Z, stride, geom, K0, Kend - K0, Kend, nr, cta);
@@ -2019,17 +2021,30 @@ static void wband_solve_launch(feasthip_ctx* h, cplx** dbases, int** dpvs, cplx*
 
 // Y[node] = (z_node B - A)^-1 RHS with the factors of fh_wband_factor.  RHS: one shared panel (row-major N x ld, the
 // library's row order); d_perm[band row] = library row (null: same order); Yb, Zb: nf work panels in band order.
-int fh_wband_solve(feasthip_ctx* h, int nf, cplx** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, cplx* Y, size_t stride,
-                   cplx* Yb, cplx* Zb, int ld, int m, int kl, int ku) {
+template <typename T>
+static int wband_solve_t(feasthip_ctx* h, int nf, T** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, size_t rhs_stride,
+                         cplx* Y, size_t stride, T* Yb, T* Zb, int ld, int m, int kl, int ku) {
     const int N = (int)h->csr.N;
     const wband_geom w = wband_geometry(N, kl, ku);
     const size_t bstride = (size_t)N * ld;
     fh_prof_begin(h, "wband_solve");
-    hipLaunchKernelGGL((k_gather_rows<cplx>), dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, (size_t)0, dperms, Yb, bstride, N, ld);
-    if (ld == 16) wband_solve_launch<16>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
-    else if (ld == 32) wband_solve_launch<32>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
-    else wband_solve_launch<64>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
-    hipLaunchKernelGGL(k_scatter_rows, dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, Yb, bstride, d_perm, Y, stride, N, ld);
+    hipLaunchKernelGGL((k_gather_rows<T>), dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, RHS, rhs_stride, dperms, Yb, bstride, N, ld);
+    if (ld == 16) wband_solve_launch<16, T>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
+    else if (ld == 32) wband_solve_launch<32, T>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
+    else wband_solve_launch<64, T>(h, dbases, dpvs, Yb, Zb, bstride, w, nf, m);
+    hipLaunchKernelGGL((k_scatter_rows<T>), dim3(fh_vec_nblk(N, ld), nf), dim3(FH_BLOCK), 0, h->stream, Yb, bstride, d_perm, Y, stride, N, ld);
     fh_prof_end(h);
     return 0;
+}
+
+// exported entry points: prec = 64 (complex128 factors) or 32 (complex64 factors; the caller refines in fp64)
+int fh_wband_factor(feasthip_ctx* h, int prec, int nf, void* const* abs_host, void** dbases, int** dpvs, const cplx* dz, int* dinfo,
+                    const int* d_iperm, int kl, int ku) {
+    if (prec == 32) return wband_factor_t<cplxf>(h, nf, abs_host, (cplxf**)dbases, dpvs, dz, dinfo, d_iperm, kl, ku);
+    return wband_factor_t<cplx>(h, nf, abs_host, (cplx**)dbases, dpvs, dz, dinfo, d_iperm, kl, ku);
+}
+int fh_wband_solve(feasthip_ctx* h, int prec, int nf, void** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, size_t rhs_stride,
+                   cplx* Y, size_t stride, void* Yb, void* Zb, int ld, int m, int kl, int ku) {
+    if (prec == 32) return wband_solve_t<cplxf>(h, nf, (cplxf**)dbases, dpvs, dperms, d_perm, RHS, rhs_stride, Y, stride, (cplxf*)Yb, (cplxf*)Zb, ld, m, kl, ku);
+    return wband_solve_t<cplx>(h, nf, (cplx**)dbases, dpvs, dperms, d_perm, RHS, rhs_stride, Y, stride, (cplx*)Yb, (cplx*)Zb, ld, m, kl, ku);
 }

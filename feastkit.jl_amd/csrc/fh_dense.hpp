@@ -33,7 +33,8 @@ int fh_dense_lu_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx*
 // matrix pointer the kernels take is storage + fh_wband_base_offset.
 size_t fh_wband_elems(int N, int kl, int ku);
 size_t fh_wband_base_offset(int N, int kl, int ku);
-int fh_wband_factor(feasthip_ctx* h, int nf, cplx* const* abs_host, cplx** dbases, int** dpvs, const cplx* dz, int* dinfo,
+// prec: 64 = complex128 factors, 32 = complex64 factors (storage elements of that type; refinement is the caller's)
+int fh_wband_factor(feasthip_ctx* h, int prec, int nf, void* const* abs_host, void** dbases, int** dpvs, const cplx* dz, int* dinfo,
                     const int* d_iperm, int kl, int ku);
-int fh_wband_solve(feasthip_ctx* h, int nf, cplx** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, cplx* Y, size_t stride,
-                   cplx* Yb, cplx* Zb, int ld, int m, int kl, int ku);
+int fh_wband_solve(feasthip_ctx* h, int prec, int nf, void** dbases, int** dpvs, int** dperms, const int* d_perm, const cplx* RHS, size_t rhs_stride,
+                   cplx* Y, size_t stride, void* Yb, void* Zb, int ld, int m, int kl, int ku);

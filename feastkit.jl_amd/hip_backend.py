@@ -272,12 +272,12 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         engine.set_solver(solver, rtol=rt, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
                           factor_precision=inner_precision)
     elif inner_precision == 32:
-        if solver in ("direct", "lu"):
-            # dense LU: complex64 factors + fp64 iterative refinement inside every solve
+        if solver in ("direct", "lu", "banded"):
+            # dense LU / blocked band LU: complex64 factors + fp64 iterative refinement inside every solve
             engine.set_solver(solver, rtol=tol_value, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
                               factor_precision=32, cache_factors=True)
         else:
-            raise ValueError("inner_precision=32 needs the dense LU solver or the warm-started inexact iterative mode")
+            raise ValueError("inner_precision=32 needs a direct solver or the warm-started inexact iterative mode")
     # -- contour policy (see the docstring): only where the filter is the real-projection filter and the solves are inexact
     auto_contour = bool(contour_policy == "auto" and contour is None and inexact and real_projection and int(fpm[16]) in (0, 1))
     policy = {"aspect": int(fpm[18]), "cap": 8000, "history": []}

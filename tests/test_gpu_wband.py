@@ -188,3 +188,36 @@ def test_blocked_band_fuzz(engine, force_blocked):
             check_solve(engine, A, B, z, m, seed=case)
         except AssertionError as exc:
             raise AssertionError(f"case {case}: n={n} band={band} density={density:.3f} m={m} cplx={cplx} sym={sym} B={'I' if B is None else 'tri'}: {exc}")
+
+
+def test_blocked_band_complex64_factors_refined(engine, force_blocked):
+    """factor_precision = 32: complex64 band factors, every solve refined in fp64 against the CSR operator -- the result
+    has fp64 accuracy (the dense solver's mixed-precision mode, on the sparse direct solver)."""
+    A, B = random_pencil(1800, 120, 0.1, 77, True, False)
+    engine.set_problem(A, B)
+    engine.set_solver("banded", rtol=1e-13, factor_precision=32)
+    kl, ku, nbytes64, blocked = engine.band_plan()
+    Y = check_solve(engine, A, B, 0.4 + 0.6j, 48, tol=5e-12)
+    assert engine.last_stats["max_rel_residual"] <= 1e-12
+    # without refinement (rtol >= 1) the same factors give single precision only
+    engine.set_solver("banded", rtol=1.0, factor_precision=32)
+    n, m = A.shape[0], 48
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
+    dY, rc = engine.shifted_solve(0.4 + 0.6j, engine.upload(X), m)
+    S = (0.4 + 0.6j) * B - A
+    res32 = np.linalg.norm(S @ engine.download(dY, m) - X) / np.linalg.norm(X)
+    assert rc == 0 and 1e-9 < res32 < 1e-1, res32             # cond x eps32 on this pencil, no more
+
+
+def test_sparse_direct_mixed_precision_full_size():
+    """cfg 3 with complex64 band factors + fp64 refinement: same eigenpairs, half the factor memory."""
+    A, B, lam = workloads.laplacian_3d_pencil(50, 40, 25)
+    inside = np.sort(lam[(lam >= 0.0) & (lam <= 0.1775)])
+    fpm = fk.feastinit(); fpm[2] = 16
+    res = fk.feast(A, B, (0.0, 0.1775), M0=64, fpm=fpm, solver="banded", inner_precision=32)
+    assert res.info == 0 and res.M == 44
+    assert np.abs(np.sort(res.lambda_) - inside).max() <= 1e-11
+    X = res.q[:, :res.M]
+    R = A @ X - (B @ X) * res.lambda_[:res.M]
+    assert (np.linalg.norm(R, axis=0) / np.maximum(np.abs(res.lambda_[:res.M]), 1.0)).max() <= 1e-11

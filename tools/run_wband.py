@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nodes", type=int, default=16)
     ap.add_argument("--interior", action="store_true")
+    ap.add_argument("--precision", type=int, default=64, help="64: complex128 band factors; 32: complex64 factors + fp64 refinement")
     ap.add_argument("--dims", type=int, nargs=3, default=(50, 40, 25))
     a = ap.parse_args()
     import torch
@@ -31,13 +32,13 @@ def main():
     t0 = time.perf_counter()
     kl, ku, nbytes, blocked = eng.band_plan()
     t_plan = time.perf_counter() - t0
-    out = {"N": n, "kl": kl, "ku": ku, "GB_per_node": nbytes / 1e9, "blocked": blocked, "ingest_s": t_ingest, "plan_s": t_plan,
+    out = {"N": n, "kl": kl, "ku": ku, "GB_per_node": nbytes / 1e9, "blocked": blocked, "precision": a.precision, "ingest_s": t_ingest, "plan_s": t_plan,
            "lu_flop_per_node": 8.0 * n * kl * (kl + ku)}
     fpm = fk.feastdefault(fk.feastinit()); fpm[2] = a.nodes
     Z, W = fk.feast_contour(0.0, 0.1775, fpm)
     eng.set_contour(Z, W, 2.0)
     eng.set_real_projection(True)
-    eng.set_solver("banded")
+    eng.set_solver("banded", rtol=1e-12, factor_precision=a.precision)
     eng.profile_enable(True)
     Q = fk.seeded_subspace(n, 64)
     dQ = eng.upload(Q)
@@ -69,7 +70,7 @@ def main():
         f = fk.feastinit(); f[2] = a.nodes
         for rep in range(2):
             t0 = time.perf_counter()
-            res = fk.feast(A, B, (lo, hi), M0=64, fpm=f, solver="banded")
+            res = fk.feast(A, B, (lo, hi), M0=64, fpm=f, solver="banded", inner_precision=a.precision)
             dt = time.perf_counter() - t0
             out[f"{name}_call{rep}"] = {"s": dt, "M": int(res.M), "info": int(res.info), "loops": int(res.loop), "epsout": float(res.epsout),
                                         "eigenpairs_per_s": res.M / dt, "want": want}
