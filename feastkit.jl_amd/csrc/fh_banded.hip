@@ -9,6 +9,8 @@
 // One workgroup per node walks the columns (the elimination is inherently sequential in j; the
 // parallelism is nodes x the (kl x (kl+ku)) window, and nodes x right-hand sides in the solves).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <vector>
 
 #include "fh_banded.hpp"
@@ -259,6 +261,16 @@ static int band_ensure_slots(feasthip_ctx* h, int nslots) {
             return FEASTHIP_ERROR_MEMORY;
         }
     }
+    const auto t_alloc = std::chrono::steady_clock::now();
+    const int had = (int)h->band_factors.size();
+    struct alloc_report {
+        feasthip_ctx* h; std::chrono::steady_clock::time_point t0; int had; size_t bytes;
+        ~alloc_report() {
+            if ((int)h->band_factors.size() > had && getenv("FH_DEBUG_TIMING"))
+                fprintf(stderr, "[feasthip] band factors: %d x %.2f GB allocated in %.1f ms\n", (int)h->band_factors.size() - had, bytes / 1e9,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    } report{h, t_alloc, had, bytes};
     while ((int)h->band_factors.size() < nslots) {
         void* f = nullptr; int* pv = nullptr;
         if (hipMalloc(&f, bytes) != hipSuccess) { (void)hipGetLastError(); h->last_error = "hipMalloc(band factor)"; return FEASTHIP_ERROR_MEMORY; }
