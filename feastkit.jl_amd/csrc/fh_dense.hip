@@ -527,6 +527,21 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                     }
                 }
             }
+        } else if constexpr (R == 1) {
+            // one row per thread: two previous columns per step, their loads in flight together (pc is a multiple of W = 16;
+            // four at a time spill 18 VGPRs).
+            // Beside the trailing product of the look-ahead a single dependent load takes microseconds; same operations in the
+            // same order on every element.
+            const bool own = rows[0] >= c0 && rows[0] < nr;
+            for (int p = 0; p < pc; p += 2) {
+                T l[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) l[q] = own ? A[(size_t)(k0 + p + q) * N + rows[0]] : LU_MK(0, 0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int w = 0; w < W; ++w) a[0][w] = csub(a[0][w], cmul(l[q], Us[p + q][w]));
+            }
         } else {
             for (int p = 0; p < pc; ++p) {
 #pragma unroll
