@@ -328,6 +328,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
 
     _blas_guard = small_lapack()
     _blas_guard.__enter__()                  # one BLAS thread for the whole solve (released before returning)
+    epsout_mp = math.inf                     # outer residual of the previous loop (refinement tolerance of complex64 factors)
     for loop_idx in range(0, maxloop + 1):
         loop_count = loop_idx
         t_ = tick()
@@ -342,6 +343,12 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
         if my_cgs > 1:
             c0, c1 = column_block(active)
             engine.set_column_block(c0, c1 - c0)
+        if inner_precision == 32 and not iterative:
+            # inexact FEAST on complex64 factors: the solves are refined only as far as the current outer residual needs
+            # (no refinement in the first loop; the last loops reach the full tolerance)
+            ref_tol = 1.0 if not math.isfinite(epsout_mp) else min(1.0, max(tol_value, 1e-2 * epsout_mp))
+            engine.set_solver(solver, rtol=ref_tol, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
+                              factor_precision=32, cache_factors=True)
         # one call = this rank's (nodes x column block) sweep + the packed all-reduce inside the C ABI:
         # dP and status come back summed over all ranks (status indexed by contour node when world > 1)
         dP, status, st = engine.contour_apply(dQ, active, lam_guess)
@@ -407,6 +414,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                     epsout = float(res.max())
                 else:
                     epsout = math.inf
+                epsout_mp = epsout
                 M_found = M
                 stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout,
                                        "krylov_iterations": st.get("krylov_iterations", 0)})
@@ -469,6 +477,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
             epsout = float(res.max())
         else:
             epsout = math.inf
+        epsout_mp = epsout
         M_found = M
         stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout, "set_aside": n_spurious,
                                "krylov_iterations": st.get("krylov_iterations", 0),
@@ -563,8 +572,8 @@ def feast_hip_general(engine, A, B, Emid, r, M0, fpm, *, solver="direct", solver
     engine.set_real_projection(False)
     first, count = distribute_contour_points(len(Zne), world)[rank]
     engine.set_node_range(first, count)
-    if inner_precision == 32 and solver not in ("direct", "lu"):
-        raise ValueError("inner_precision=32 (complex64 LU factors + fp64 refinement) needs the dense LU solver")
+    if inner_precision == 32 and solver not in ("direct", "lu", "banded"):
+        raise ValueError("inner_precision=32 (complex64 LU factors + fp64 refinement) needs a direct solver")
     engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
                       restart=solver_restart, cache_factors=True, factor_precision=32 if inner_precision == 32 else 64)
     Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
