@@ -1984,7 +1984,7 @@ static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** db
             gemm(K0, WB, Kend, nr, a, b);
         };
         const int Kend2 = lookahead ? std::min(nc, Kend + WB) : nc;
-        right_of_block(Kend, Kend2);
+        // the rest needs the block column's panels only, not the next block column's update: it starts beside that update
         if (Kend2 < nc) {
             hipError_t er = hipEventRecord(h->lu_ev_next, main_s);
             if (er == hipSuccess) er = hipStreamWaitEvent(h->side_stream, h->lu_ev_next, 0);
@@ -1996,6 +1996,7 @@ static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** db
             if (er != hipSuccess) { h->last_error = "hipEventRecord(band LU)"; return FEASTHIP_ERROR_INTERNAL; }
             rest_pending = true;
         }
+        right_of_block(Kend, Kend2);
     }
     if (rest_pending && hipStreamWaitEvent(main_s, h->lu_ev_rest, 0) != hipSuccess) { h->last_error = "hipStreamWaitEvent(band LU)"; return FEASTHIP_ERROR_INTERNAL; }
     hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3((N + LU_NB - 1) / LU_NB, nf), dim3(64), 0, h->stream, dbases, geom);
