@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
     const T* A = LUs[node];
     const int N = g.ld, NBND = g.n;
     const T* invbase = A + g.inv32;
-    if (IDENT) { K0 = blockIdx.y * SOLVE_KB; kb = min(SOLVE_KB / LU_NB, (NBND - K0 + LU_NB - 1) / LU_NB); }
+    if (IDENT) { K0 += blockIdx.y * SOLVE_KB; kb = min(SOLVE_KB / LU_NB, (NBND - K0 + LU_NB - 1) / LU_NB); }   // K0: first block of the launch
     const T* in = IN + (size_t)node * stride;
     T* out = OUT + (size_t)node * stride;
     const int ta = blockIdx.x;
@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag(T* const* LUs, T* IN, T
         __syncthreads();
     }
     if (IDENT) {
-        T* inv128 = LUs[node] + g.inv128 + ((size_t)blockIdx.y * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
+        T* inv128 = LUs[node] + g.inv128 + ((size_t)(K0 / SOLVE_KB) * 2 + (UPPER ? 1 : 0)) * SOLVE_KB * SOLVE_KB;
         for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
             const int i = e & (SOLVE_KB - 1), c = e / SOLVE_KB;
             inv128[(size_t)(16 * ta + c) * SOLVE_KB + i] = S[i][c];
@@ -1308,6 +1308,64 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_diag_inv(T* const* LUs, T* I
         const int i0 = 16 * t0 + lu_el<T>::mrow(lk, r), i1 = 16 * t1 + lu_el<T>::mrow(lk, r);
         if (i0 < LU_NB * kb && K0 + i0 < g.n) out[(size_t)(K0 + i0) * LD + 16 * ta + lr] = LU_MK(re0[r], im0[r]);
         if (i1 < LU_NB * kb && K0 + i1 < g.n) out[(size_t)(K0 + i1) * LD + 16 * ta + lr] = LU_MK(re1[r], im1[r]);
+    }
+}
+
+// U block row of a whole 128-column block at once (band LU): A[K0:K0+128, c] = L11^-1 A[K0:K0+128, c] for the columns
+// c in [c0, c1) of the column-major factor, L11^-1 the 128 x 128 inverse k_solve_diag<IDENT> leaves behind the factor.  The
+// product is k_solve_diag_inv's (one workgroup per 16 columns, wave w the output tiles w and 7 - w); only the slab is read
+// and written along columns instead of panel rows.  Replaces four L11^-1 products of 32 rows and three k = 32 row-block
+// products per block column and side of the look-ahead.
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm128(T* const* LUs, lu_geom g, int K0, int c0, int c1) {
+    constexpr int NT = SOLVE_KB / 16;
+    T* A = LUs[blockIdx.y];
+    const T* inv = A + g.inv128 + ((size_t)(K0 / SOLVE_KB) * 2) * SOLVE_KB * SOLVE_KB;
+    const int cbase = c0 + 16 * blockIdx.x;
+    __shared__ T S[SOLVE_KB][17];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int t0 = wave, t1 = NT - 1 - wave;
+    const int n0 = t0 + 1;
+    T a[NT + 1][4];
+#pragma unroll
+    for (int q = 0; q <= NT; ++q) {
+        const int tile = q < n0 ? t0 : t1, blk = q < n0 ? q : q - n0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) a[q][s4] = inv[(size_t)(16 * blk + 4 * s4 + lk) * SOLVE_KB + 16 * tile + lr];
+    }
+    for (int e = t; e < SOLVE_KB * 16; e += FH_BLOCK) {
+        const int i = e & (SOLVE_KB - 1), c = e / SOLVE_KB;      // consecutive threads: consecutive rows of one column
+        S[i][c] = (cbase + c < c1) ? A[(size_t)(cbase + c) * g.ld + K0 + i] : LU_MK(0, 0);
+    }
+    __syncthreads();
+    typename lu_el<T>::v4 re0 = {0, 0, 0, 0}, im0 = {0, 0, 0, 0}, re1 = {0, 0, 0, 0}, im1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q <= NT; ++q) {
+        const int blk = q < n0 ? q : q - n0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const T b = S[16 * blk + 4 * s4 + lk][lr];
+            if (q < n0) {
+                re0 = lu_el<T>::mfma(a[q][s4].x, b.x, re0);
+                re0 = lu_el<T>::mfma(-a[q][s4].y, b.y, re0);
+                im0 = lu_el<T>::mfma(a[q][s4].x, b.y, im0);
+                im0 = lu_el<T>::mfma(a[q][s4].y, b.x, im0);
+            } else {
+                re1 = lu_el<T>::mfma(a[q][s4].x, b.x, re1);
+                re1 = lu_el<T>::mfma(-a[q][s4].y, b.y, re1);
+                im1 = lu_el<T>::mfma(a[q][s4].x, b.y, im1);
+                im1 = lu_el<T>::mfma(a[q][s4].y, b.x, im1);
+            }
+        }
+    }
+    if (cbase + lr < c1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i0 = 16 * t0 + lu_el<T>::mrow(lk, r), i1 = 16 * t1 + lu_el<T>::mrow(lk, r);
+            A[(size_t)(cbase + lr) * g.ld + K0 + i0] = LU_MK(re0[r], im0[r]);
+            A[(size_t)(cbase + lr) * g.ld + K0 + i1] = LU_MK(re1[r], im1[r]);
+        }
     }
 }
 
@@ -1945,6 +2003,7 @@ static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** db
     // L columns and pivots of block b and writes only columns >= Kend + WB; block column b+1 writes only its own columns and
     // pivots until it waits for the rest (its interchanges to the right touch the same columns).  No interchanges go to the
     // left in the band factorisation, so nothing else is shared.  Same operations on every element: identical factors.
+    static const bool block_inverse = !(getenv("FH_WBAND_BLOCKINV") && atoi(getenv("FH_WBAND_BLOCKINV")) == 0);
     bool lookahead = h->lu_lookahead != 0 && kl + ku > 2 * WB && N > 4 * WB;
     if (lookahead && !lu_side_stream(h, lu_lookahead_reserve(nf))) lookahead = false;
     const hipStream_t main_s = h->stream;
@@ -1977,12 +2036,21 @@ static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** db
         auto right_of_block = [&](int a, int b) {
             if (a >= b) return;
             laswp(K0, Kend - K0, 0, 0, a, b);
-            for (int k0 = K0; k0 < Kend; k0 += LU_NB) {        // Kend - K0 == WB here
-                trsm(k0, LU_NB, a, b);
-                gemm(k0, LU_NB, k0 + LU_NB, Kend, a, b);
+            if (block_inverse) {                               // Kend - K0 == WB here
+                hipLaunchKernelGGL((k_lu_trsm128<T>), dim3((b - a + 15) / 16, nf), dim3(FH_BLOCK), 0, h->stream, dbases, geom, K0, a, b);
+            } else {
+                for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
+                    trsm(k0, LU_NB, a, b);
+                    gemm(k0, LU_NB, k0 + LU_NB, Kend, a, b);
+                }
             }
             gemm(K0, WB, Kend, nr, a, b);
         };
+        // the 128 x 128 inverse of the block column's unit-lower L11 (from the 32-block inverses the panels left): the U block
+        // row right of it is then ONE product per side of the look-ahead instead of four 32-row products and three k = 32
+        // row-block products (FH_WBAND_BLOCKINV=0: the 32-row sequence)
+        if (block_inverse)
+            hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), dim3(SOLVE_KB / 16, 1, nf), dim3(FH_BLOCK), 0, h->stream, dbases, (T*)nullptr, (T*)nullptr, (size_t)0, geom, K0, 0);
         const int Kend2 = lookahead ? std::min(nc, Kend + WB) : nc;
         // the rest needs the block column's panels only, not the next block column's update: it starts beside that update
         if (Kend2 < nc) {
