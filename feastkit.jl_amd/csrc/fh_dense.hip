@@ -1581,6 +1581,9 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
     // measured (cfg 2 / cfg 5): at N = 4096 a 256-wide outer block is neutral, at N = 8192 it saves 4-6 % (the k = 256
     // trailing product runs at 52 instead of 46 TFLOP/s and outweighs the longer k = 32 in-block updates)
     const int KB = h->lu_outer_block > 0 ? h->lu_outer_block : (N >= 6144 ? 256 : 128);
+    // (FH_LU_BLOCKINV=0: the U block row by 32-row products; needs whole 128-row slabs and the register-resident panels' inverses)
+    static const bool blockinv_off = getenv("FH_LU_BLOCKINV") && atoi(getenv("FH_LU_BLOCKINV")) == 0;
+    const bool block_inverse = !blockinv_off && !trsm_subst && KB % SOLVE_KB == 0 && !h->lu_panel_legacy && N <= 16 * LU_PANEL_THREADS;
     // Look-ahead: the panels of a block column run one 1024-thread workgroup per matrix (8 or 24 of 256 CUs), so the
     // trailing update of block column b is split by columns -- the NEXT block column [Kend, Kend2) is updated on the
     // main stream, the REST [Kend2, N) on a side stream -- and the panels / in-block products of block column b+1
@@ -1625,6 +1628,16 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         // the block column's interchanges, U block row and trailing update on columns [a, b) right of it
         auto right_of_block = [&](int a, int b, int chunks) {
             if (Kend >= N || a >= b) return;   // Kend - K0 == KB from here
+            if (block_inverse) {
+                // U block row by 128-row slabs: one product with the slab's 128 x 128 inverse of L11 (k_lu_trsm128), one
+                // k = 128 update of the slabs below it -- instead of four 32-row products and four k = 32 updates per slab
+                for (int k1 = K0; k1 < Kend; k1 += SOLVE_KB) {
+                    fh_prof_begin(h, "lu_trsm");
+                    hipLaunchKernelGGL((k_lu_trsm128<T>), dim3((b - a + 15) / 16, nf), dim3(FH_BLOCK), 0, h->stream, dlus, geom, k1, a, b);
+                    fh_prof_end(h);
+                    if (k1 + SOLVE_KB < Kend) gemm(k1, SOLVE_KB, k1 + SOLVE_KB, Kend, a, b, "lu_gemm_in");
+                }
+            } else
             for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
                 trsm(k0, a, b);
                 gemm(k0, LU_NB, k0 + LU_NB, Kend, a, b, "lu_gemm_in");
@@ -1635,6 +1648,9 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
             for (int c = a; c < b; c += step) gemm(K0, KB, Kend, N, c, std::min(b, c + step), "lu_gemm");
         };
         const int Kend2 = lookahead ? std::min(N, Kend + KB) : N;
+        if (block_inverse && Kend < N)      // 128 x 128 inverses of the block column's unit-lower diagonal slabs (from the panels' 32-block inverses)
+            hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), dim3(SOLVE_KB / 16, (Kend - K0) / SOLVE_KB, nf), dim3(FH_BLOCK), 0, h->stream, dlus,
+                               (T*)nullptr, (T*)nullptr, (size_t)0, geom, K0, 0);
         laswp(K0, Kend - K0, 0, K0, Kend, Kend2);
         right_of_block(Kend, Kend2, 1);
         if (Kend2 < N) {
