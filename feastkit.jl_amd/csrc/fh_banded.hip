@@ -309,6 +309,7 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
     info_out.assign(nf, 0);
     if (nf == 0) return 0;
     const int N = (int)h->csr.N, kl = h->band_kl, ku = h->band_ku;
+    const auto t_factor = std::chrono::steady_clock::now();
     void* p;
     int rc;
     cplx** dabs; int** dpvs; int** dperms;
@@ -343,6 +344,9 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
     }
     FH_CHECK(hipMemcpyAsync(info_out.data(), dinfo, nf * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
+    if (getenv("FH_DEBUG_TIMING"))
+        fprintf(stderr, "[feasthip] band LU: %d factorisations (plan %d, kl %d ku %d, %d-bit) in %.1f ms\n", nf, h->band_plan, kl, ku, h->band_prec,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_factor).count());
     return 0;
 }
 
