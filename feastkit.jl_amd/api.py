@@ -3,6 +3,7 @@
 package provides.  Everything else of the reference API stays on the Julia host."""
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -48,7 +49,15 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30, dense_limit=12288)
     return "krylov"
 
 
-def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False):
+# `solver=:direct` on a sparse Hermitian pencil beyond the narrow-band / dense windows: the band LU is taken outright when all
+# its factorisations together cost at most this many flop (8 N kl (kl + ku) per node), else the Krylov path runs first with
+# the direct solver as its fallback.  OFF by default (0): the block steps of the band LU are a chain of panel kernels, ~0.4 s
+# for N = 50 000 however thin the band, and the inexact Krylov path is at 0.3 s on the 2-D / thin 3-D pencils tried (first
+# calls, N = 50 000: 400 x 125 grid 0.48 s direct / 0.53 s Krylov; 160 x 160 x 2: 0.72 / 0.30; 100 x 100 x 5: 0.76 / 0.30).
+_DIRECT_FLOPS = float(os.environ.get("FEASTKIT_DIRECT_FLOPS", "0"))
+
+
+def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False, max_flops=1e14):
     """True when the sparse direct solver for general patterns (reverse Cuthill-McKee + blocked band LU on the dense
     kernels, FEASTHIP_SOLVER_BANDED) can hold one factor per local quadrature node in the free device memory.  Sets the
     problem on the engine (a later set_problem with the same matrices is free: content fingerprint)."""
@@ -71,7 +80,7 @@ def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False):
     # the elimination costs 8 N kl (kl + ku) flop per node: beyond ~1e14 in all (seconds of MFMA time) a band this wide is no
     # longer the cheap way to a direct solve
     flops = 8.0 * A.shape[0] * kl * (kl + ku) * local
-    return (local + 1) * nbytes + panels <= 0.85 * free and flops <= 1e14
+    return (local + 1) * nbytes + panels <= 0.85 * free and flops <= max_flops
 
 
 def _single_precision(*mats):
@@ -181,6 +190,14 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         if solver == "dense":
             A, B, solver = _densify(A), _densify(B), "direct"
             substituted = {"requested": "direct", "used": "dense LU of the expanded matrix"}
+        elif solver == "krylov" and group is None and _band_direct_fits(eng, A, B, int(fpm[2]), max_flops=_DIRECT_FLOPS):
+            # a band the direct solver eliminates in a fraction of a second (2-D problems, thin 3-D ones): the reference's own
+            # default -- a direct factorisation per node, exact solves, two or three loops -- is then also the faster one
+            # (measured: DESIGN.md section 5); wider bands keep the Krylov fast path with the direct solver as its fallback
+            solver = "banded"
+            substituted = {"requested": "direct", "used": "band LU after reverse Cuthill-McKee"}
+            if fp is not None and fp[0] and fp[1] is not False:
+                eng._checked = {"fp": fp, "nodes": int(fpm[2]), "direct": solver}
         elif solver == "krylov":
             solver = "cocg" if real_input else "bicgstab"
             # each default applies on its own: naming one of the three keeps the other two

@@ -172,12 +172,14 @@ __global__ __launch_bounds__(FH_BLOCK) void k_band_solve(cplx* const* ABs, int* 
 // host orchestration
 //
 // Band plan (made once per matrix, on first use).  The pattern is measured in the order it is stored on the device (the
-// ingest may have renumbered it).  A band of at most FH_BAND_NARROW (512) in that order goes to the one-workgroup
-// elimination above.  Anything wider is renumbered by reverse Cuthill-McKee (fh_ingest.hpp) if that narrows it and goes to
+// ingest may have renumbered it).  A band of at most FH_BAND_NARROW (kl + ku <= 64) in that order goes to the one-workgroup
+// elimination above: it walks the columns one by one (two barriers each, the window through one CU), which is fine for a
+// few diagonals and hopeless for hundreds -- a 250 x 200 grid (kl = ku = 250, N = 50 000) took 6.6 s there against 0.5 s
+// in the blocked solver.  Anything wider is renumbered by reverse Cuthill-McKee (fh_ingest.hpp) if that narrows it and goes to
 // the blocked band LU on the dense kernels (fh_dense.hip, fh_wband_*): the sparse direct solver for general patterns.
 // FH_WBAND=1 sends every matrix there (tests).
 // ---------------------------------------------------------------------------------------
-#define FH_BAND_NARROW 512
+#define FH_BAND_NARROW 64
 
 void fh_banded_free(feasthip_ctx* h) {
     for (void* p : h->band_factors) if (p) hipFree(p);
