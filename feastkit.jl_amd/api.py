@@ -3,6 +3,7 @@
 package provides.  Everything else of the reference API stays on the Julia host."""
 from __future__ import annotations
 
+import math
 import os
 import warnings
 
@@ -221,19 +222,52 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
                 substituted["contour_policy"] = "auto"
     if solver == "sparse_direct":
         solver = "banded"
+    abort_check = None
+    if (substituted is not None and substituted.get("used") in ("cocg", "bicgstab") and group is None
+            and os.environ.get("FEASTKIT_DIRECT_SWITCH", "1") != "0"):
+        # (FEASTKIT_DIRECT_SWITCH=0: never leave the Krylov path before fpm[4] loops are spent.)  The Krylov path was OUR choice for the caller's solver=:direct.  After every refinement loop the time it still needs
+        # is extrapolated from the contraction of the outer residual over the last two loops; when that exceeds 3 x what
+        # the sparse direct solver would take from here (its factorisations: a chain of ~1.5 ms block steps plus
+        # 8 N kl (kl + ku) flop per node at ~20 TFLOP/s; then one or two loops), the sweep stops and the direct solver
+        # finishes from the current subspace.  Intervals inside the spectrum, where the Krylov sweeps stagnate, cost four
+        # loops of them instead of fpm[4].
+        plan = {}
+
+        def abort_check(loop_idx, eps, elapsed):
+            if loop_idx < 3:
+                return False
+            if "t_direct" not in plan:
+                plan["t_direct"] = None
+                if _band_direct_fits(eng, A, B, int(fpm[2])):
+                    kl, ku, _nb, _blk = eng.band_plan()
+                    plan["t_direct"] = 0.3 + (N / 128.0) * 1.5e-3 + 8.0 * N * kl * (kl + ku) * int(fpm[2]) / 2e13
+            if plan["t_direct"] is None:
+                return False
+            fin = [e for e in eps if np.isfinite(e) and e > 0]
+            tol = 10.0 ** (-int(fpm[3]))
+            if len(fin) >= 3 and len(eps) >= 3 and all(np.isfinite(e) for e in eps[-3:]):
+                rho = (eps[-1] / eps[-3]) ** 0.5
+                remaining = math.inf if rho >= 1.0 else max(0.0, math.log(tol / eps[-1]) / math.log(rho)) * (elapsed / (loop_idx + 1))
+            else:
+                remaining = math.inf                                    # no Ritz value inside after four loops
+            return remaining > 3.0 * plan["t_direct"]
     warm_start = bool(warm_start)                 # an explicitly named iterative solver keeps the reference's zero guess
     solver_maxiter = 500 if solver_maxiter is None else int(solver_maxiter)
     res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver=solver, solver_tol=solver_tol,
                               solver_maxiter=solver_maxiter, solver_restart=solver_restart,
                               warm_start=warm_start, inner_rtol=inner_rtol, real_projection=real_projection,
                               inner_precision=inner_precision, group=group, Q0=Q0, contour=contour,
-                              contour_policy=contour_policy, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
+                              contour_policy=contour_policy, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0,
+                              abort_check=abort_check)
     if (res.info == 5 and substituted is not None and substituted.get("used") in ("cocg", "bicgstab") and group is None
             and _band_direct_fits(eng, A, B, int(fpm[2]))):
         # The Krylov sweeps did not converge (typically an interval inside the spectrum: the shifted systems are then
         # indefinite and badly conditioned).  solver=:direct was what the caller asked for, and the direct solver for general
         # patterns fits the device: run it, as the reference's default would have from the start.
         krylov_info, krylov_loops = int(res.info), int(res.loop)
+        # (the direct solver starts from the caller's / the seeded subspace, not from what the Krylov loops left: measured on
+        #  cfg 3's interval around 2.0, the stagnated subspace carries a spurious pair into the direct solve -- M = 41, info 5
+        #  after 20 loops -- where the fresh start converges in two)
         res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver="banded", solver_tol=solver_tol,
                                   real_projection=real_projection, inner_precision=inner_precision, group=group, Q0=Q0,
                                   contour=contour, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)

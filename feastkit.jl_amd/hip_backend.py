@@ -160,7 +160,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
                         preloaded=False, node_assignment="block", inner_precision=64, column_groups=1,
-                        spurious_filter=True, contour_policy=None, eps_floor=0.0):
+                        spurious_filter=True, contour_policy=None, eps_floor=0.0, abort_check=None):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -329,6 +329,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     _blas_guard = small_lapack()
     _blas_guard.__enter__()                  # one BLAS thread for the whole solve (released before returning)
     epsout_mp = math.inf                     # outer residual of the previous loop (refinement tolerance of complex64 factors)
+    t_loops = time.perf_counter()
     for loop_idx in range(0, maxloop + 1):
         loop_count = loop_idx
         t_ = tick()
@@ -486,6 +487,12 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
             break
         if loop_idx == maxloop:
             info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            break
+        if abort_check is not None and world == 1 and abort_check(loop_idx, [l["epsout"] for l in stats["loops"]],
+                                                                  time.perf_counter() - t_loops):
+            # the caller has a cheaper way to finish (api.feast: the sparse direct solver): stop here
+            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+            stats["aborted"] = True
             break
         if inexact:
             # stagnation guard: the outer residual should contract by about inner_rtol per loop.  When it has not even

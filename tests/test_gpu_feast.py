@@ -240,18 +240,27 @@ def test_cfg3_reference_default_call_full_size(engine):
     assert rc.stats["krylov_iterations"] > 2 * r.stats["krylov_iterations"]      # what the policy is for
 
 
-def test_default_call_interior_interval_full_size(engine):
+@pytest.mark.parametrize("switch", ["1", "0"])
+def test_default_call_interior_interval_full_size(engine, switch, monkeypatch):
     """The default call on an INTERIOR interval of cfg 3's pencil (40 eigenvalues around 0.52: guards on both sides,
-    indefinite shifted systems): the contour policy must still deliver every eigenpair (measured: 1.5 s against 9.2 s on the
-    circle).  Deep inside the spectrum, where 40 eigenvalues span 1e-2 at lambda = 2, no unpreconditioned Krylov sweep
-    converges on any contour (circle and policy both end with info 5): that is the direct solver's territory."""
+    indefinite shifted systems).  With the Krylov path alone (FEASTKIT_DIRECT_SWITCH=0) the contour policy still delivers
+    every eigenpair (measured: 1.8 s, 14 loops, against 9.2 s on the circle).  By default the call extrapolates the time the
+    Krylov loops still need after each of them and, here, hands over to the sparse direct solver after four (1.3 s).  Deep
+    inside the spectrum, where 40 eigenvalues span 1e-2 at lambda = 2, no unpreconditioned Krylov sweep converges on any
+    contour: tests/test_gpu_wband.py."""
+    monkeypatch.setenv("FEASTKIT_DIRECT_SWITCH", switch)
     A, B, lam = fo.cfg3_problem(50, 40, 25)
     i0 = int(np.searchsorted(lam, 0.5))
     lo, hi = 0.5 * (lam[i0 - 1] + lam[i0]), 0.5 * (lam[i0 + 39] + lam[i0 + 40])
     r = fk.feast(A, B, (lo, hi), M0=64, fpm=fpm_with(f2=16, f4=40), engine=engine)
     assert r.info == 0 and r.M == 40 and np.abs(np.sort(r.lambda_) - lam[i0:i0 + 40]).max() <= 1e-10
     res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
-    assert res.max() <= 1e-11 and min(r.stats["contour_policy"]["fpm18_per_loop"]) > 100
+    assert res.max() <= 1e-11
+    sub = r.stats["solver_substitution"]
+    if switch == "0":
+        assert "fallback" not in sub and min(r.stats["contour_policy"]["fpm18_per_loop"]) > 100
+    else:
+        assert sub.get("fallback", "").startswith("band LU") and sub["krylov_loops"] <= 6 and r.loop <= 3
 
 
 _PENCILS = {"diag_mass_3d": ((50, 40, 25), "diag_mass"), "stiff_mass_3d": ((50, 40, 25), "stiff_mass"), "diag_mass_2d": ((400, 125), "diag_mass")}
