@@ -221,3 +221,35 @@ def test_sparse_direct_mixed_precision_full_size():
     X = res.q[:, :res.M]
     R = A @ X - (B @ X) * res.lambda_[:res.M]
     assert (np.linalg.norm(R, axis=0) / np.maximum(np.abs(res.lambda_[:res.M]), 1.0)).max() <= 1e-11
+
+
+def test_sparse_general_direct_beyond_the_dense_window():
+    """The sparse GENERAL driver with every keyword at its default on a non-symmetric 3-D convection-diffusion operator
+    (N = 17 920, 7-point pattern: beyond the dense window), the eigenvalues in a disc at the lower end of the spectrum.  The
+    default `solver=:direct` is served by the sparse direct solver (16 full-contour factorisations of the reordered band);
+    checker: ARPACK shift-invert on SuperLU factors."""
+    nx, ny, nz = 32, 28, 20
+
+    def d2(n):
+        return sp.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+
+    def d1(n):
+        return sp.diags([-np.ones(n - 1), np.ones(n - 1)], [-1, 1], format="csr")          # central difference: skew-symmetric
+    Ix, Iy, Iz = sp.identity(nx), sp.identity(ny), sp.identity(nz)
+    lap = sp.kron(Iz, sp.kron(Iy, d2(nx))) + sp.kron(Iz, sp.kron(d2(ny), Ix)) + sp.kron(d2(nz), sp.kron(Iy, Ix))
+    conv = 0.3 * sp.kron(Iz, sp.kron(Iy, d1(nx))) + 0.2 * sp.kron(Iz, sp.kron(d1(ny), Ix))
+    A = sp.csr_matrix(lap + conv)
+    assert abs(A - A.T).max() > 0.1 and fk.api._sparse_direct_solver(A, None, 16) == "krylov"
+    ref = spla.eigs(A.tocsc().astype(complex), k=32, sigma=0.0, which="LM", return_eigenvectors=False, tol=1e-12)
+    ref = ref[np.argsort(np.abs(ref))]
+    radius = 0.5 * (abs(ref[20]) + abs(ref[21]))                   # the widest gap nearby: 21 eigenvalues inside
+    inside = ref[np.abs(ref) < radius]
+    assert inside.size == 21
+    fpm = fk.feastinit(); fpm[8] = 16
+    res = fk.feast_general(A, None, 0.0, radius, M0=inside.size, fpm=fpm)
+    assert res.stats["solver_substitution"]["used"].startswith("band LU") and res.stats["factorizations"] == 16
+    assert res.info == 0 and res.M == inside.size
+    key = lambda z: (round(z.real, 8), round(z.imag, 8))
+    assert np.allclose(sorted(res.lambda_, key=key), sorted(inside, key=key), atol=1e-9)
+    R = A @ res.q - res.q * res.lambda_
+    assert (np.linalg.norm(R, axis=0) / np.linalg.norm(res.q, axis=0)).max() <= 1e-10
