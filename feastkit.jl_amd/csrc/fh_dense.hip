@@ -1447,7 +1447,11 @@ __global__ __launch_bounds__(FH_BLOCK) void k_solve_update(T* const* LUs, T* IN,
 // ---------------------------------------------------------------------------------------
 // The side stream of the LU look-ahead (dense and band factorisations): created with a CU mask that leaves `reserve` CUs per
 // XCD to the main stream.  Returns false (and switches the look-ahead off for the handle) when no second stream can be had.
-static int lu_lookahead_reserve(int nf) { return getenv("FH_LU_RESERVE") ? atoi(getenv("FH_LU_RESERVE")) : std::min(4, (nf + 7) / 8); }
+// CUs per XCD kept out of the side stream's mask.  One per panel workgroup an XCD receives ((nf + 7) / 8) was the first choice;
+// measured later with FH_LU_RESERVE = 2 / 4 / 8: band LU of cfg 3 (16 nodes) 583 / 502 / 500 ms, dense cfg 2 (8 nodes) 79 / 76 /
+// 77 ms against 82 at one, cfg 5 (24 nodes) unchanged -- the main stream's small kernels run on the reserved CUs too, and a
+// panel workgroup needs a completely empty one.
+static int lu_lookahead_reserve(int nf) { (void)nf; return getenv("FH_LU_RESERVE") ? atoi(getenv("FH_LU_RESERVE")) : 4; }
 static bool lu_side_stream(feasthip_ctx* h, int reserve) {
     // CUs per XCD left to the main stream: one per panel workgroup the XCD receives (workgroups go round-robin over XCDs)
     if (!h->side_stream || h->side_reserve != reserve) {
