@@ -13,14 +13,14 @@ from .contour import (feast_contour, feast_gcontour, feast_inside_gcontour, zolo
                       distribute_contour_points, balanced_contour_points, cost_balanced_contour_points)
 from . import workloads   # noqa: F401
 from .hip_backend import (feast_hip_hermitian, feast_hip_general, feast_hip_complex_symmetric,   # noqa: F401
-                          pfeast_hip_moments, pfeast_hip_hermitian_moments, seeded_subspace)   # noqa: F401
+                          pfeast_hip_moments, pfeast_hip_hermitian_moments, feast_hip_symmetric_kernel,
+                          seeded_subspace)   # noqa: F401
 from .engine import HipEngine   # noqa: F401
 from .api import feast, feast_general   # noqa: F401
 from . import rci   # noqa: F401
 from . import ingest   # noqa: F401
 from . import banded   # noqa: F401
 from .banded import feast_sbgv, feast_sbev, feast_hbgv, feast_hbev, feast_gbgv, feast_gbev   # noqa: F401
-from .rci import (RciRefs, RciState, HipRciServer, feast_srci, feast_hrci, feast_grci,   # noqa: F401
-                  rci_solve_symmetric, rci_solve_hermitian, rci_solve_general)
+from .rci import HipRciServer   # noqa: F401
 
 __version__ = "0.1.0"

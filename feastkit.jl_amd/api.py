@@ -66,22 +66,30 @@ def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False, max_flops=
     if complexify:
         A = A.astype(np.complex128) if not np.iscomplexobj(A.data) else A
         B = None if B is None else (B.astype(np.complex128) if not np.iscomplexobj(B.data) else B)
-    try:
-        eng.set_problem(A, B)
-        kl, ku, nbytes, blocked = eng.band_plan()
-    except FeastHipError:
-        return False
     world = 1
     if group is not None:
         import torch.distributed as dist
         world = dist.get_world_size(group)
     local = -(-max(int(nodes), 1) // world)
-    free, _total = torch.cuda.mem_get_info(eng.device)
-    panels = 2 * local * A.shape[0] * 64 * 16
-    # the elimination costs 8 N kl (kl + ku) flop per node: beyond ~1e14 in all (seconds of MFMA time) a band this wide is no
-    # longer the cheap way to a direct solve
-    flops = 8.0 * A.shape[0] * kl * (kl + ku) * local
-    return (local + 1) * nbytes + panels <= 0.85 * free and flops <= max_flops
+    try:
+        eng.set_problem(A, B)
+        kl, ku, nbytes, blocked = eng.band_plan()
+        free, _total = torch.cuda.mem_get_info(eng.device)
+        panels = 2 * local * A.shape[0] * 64 * 16
+        # the elimination costs 8 N kl (kl + ku) flop per node: beyond ~1e14 in all (seconds of MFMA time) a band this wide
+        # is no longer the cheap way to a direct solve
+        flops = 8.0 * A.shape[0] * kl * (kl + ku) * local
+        fits = bool((local + 1) * nbytes + panels <= 0.85 * free and flops <= max_flops)
+    except FeastHipError:
+        fits = False
+    if world > 1:
+        # every rank decides from ITS free memory: the ranks must agree (different solvers have different tolerance
+        # semantics, and a rank that alone takes the band LU would fail later in its slot allocation) -- logical AND over
+        # the group, through the control plane (any backend)
+        votes = [None] * world
+        dist.all_gather_object(votes, fits, group=group)
+        fits = all(votes)
+    return fits
 
 
 def _single_precision(*mats):
@@ -136,18 +144,37 @@ def _warn_substitution(sub):
                   RuntimeWarning, stacklevel=3)
 
 
+def _release_band_factors(eng, keep):
+    """The sparse direct solver's factors stay on the engine across set_contour and across calls (16 x 2.8 GB on cfg 3).
+    Inside one call that is the reference's factor cache; beyond it, it is device memory a later Krylov / GMRES call on
+    the same engine no longer has (and that _band_direct_fits would count as taken).  Whatever path of the call created
+    them -- solver='banded', the automatic choice of feast_general, the Krylov-to-direct fallback -- they go when the
+    call returns unless the caller asked to keep them."""
+    if keep:
+        return
+    try:
+        eng.free_factors()
+    except FeastHipError:
+        pass                                   # a poisoned handle reports through the result, not from the clean-up
+
+
 def _engine(engine, device):
     return engine if engine is not None else HipEngine(device)
 
 
 def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="direct", solver_tol=0.0,
           solver_maxiter=None, solver_restart=30, warm_start=None, inner_rtol=None, real_projection=None,
-          inner_precision=64, group=None, engine=None, device=0, Q0=None, contour=None, contour_policy=None):
+          inner_precision=64, group=None, engine=None, device=0, Q0=None, contour=None, contour_policy=None,
+          keep_factors=False):
     """feast(A, [B,] (Emin, Emax); M0, fpm, backend=:hip) for real-symmetric / Hermitian
     dense (numpy) or sparse (scipy) matrices.  Real input is complexified and the result is
     real.(q), exactly as feast_sygv!/feast_scsrgv! do (src/dense/feast_dense.jl:362-387).
     ``contour=(Zne, Wne)``: caller-supplied half-contour nodes and weights, the reference's "x" drivers
     (feast_hcsrgvx!/feast_heevx!, test/runtests.jl:415-440).
+    ``keep_factors``: the band-LU factors of the sparse direct solver (one per quadrature node: 2.8 GB each on cfg 3) are
+    cached across the refinement loops of ONE call, like the reference's per-call ``lu(zB - A)`` cache
+    (src/sparse/feast_sparse.jl:335-341), and released when the call returns; ``True`` leaves them resident on the engine
+    for a repeated call on the same contour (``engine.free_factors()`` releases them).
     """
     if interval is None and B is not None and isinstance(B, tuple):
         B, interval = None, B              # feast(A, (Emin, Emax)) form
@@ -275,6 +302,7 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
                            krylov_loops=krylov_loops)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
+    _release_band_factors(eng, keep_factors)
     if real_input:
         res = FeastResult(res.lambda_, np.real(res.q), res.M, res.res, res.info, res.epsout, res.loop, res.stats)
     if single:
@@ -284,8 +312,9 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
 
 def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend="hip", solver="direct",
                   solver_tol=0.0, solver_maxiter=500, solver_restart=30, group=None, engine=None, device=0, Q0=None,
-                  inner_precision=64, contour=None):
-    """feast_general(A, [B,] center, radius; M0, fpm): src/interfaces/feast_interfaces.jl:274-379."""
+                  inner_precision=64, contour=None, keep_factors=False):
+    """feast_general(A, [B,] center, radius; M0, fpm): src/interfaces/feast_interfaces.jl:274-379.
+    ``keep_factors``: as in feast()."""
     if backend not in _BACKENDS:
         raise ValueError(f"Unknown backend '{backend}' (this package provides: hip)")
     if A.shape[0] != A.shape[1]:
@@ -331,6 +360,7 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
                              eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
+    _release_band_factors(eng, keep_factors)
     if single:
         res = _demote(res, cplx_lambda=True)
     return res

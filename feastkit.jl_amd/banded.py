@@ -4,7 +4,7 @@ libfeasthip.so (``solver="direct"`` -> FEASTHIP_SOLVER_BANDED) and the band mat-
 kernels.  Band storage is the reference's: upper (k+1) x N for symmetric / Hermitian matrices,
 (2k+1) x N for general ones (feast_banded.jl:1-7, 205-271, 488-509).
 
-  feast_sbgv / feast_sbev   real symmetric       -> RCI kernel feast_srci!  (:9-186, 1410-1432)
+  feast_sbgv / feast_sbev   real symmetric       -> the maths of feast_srci! (:9-186, 1410-1432)
   feast_hbgv / feast_hbev   complex Hermitian    -> variant A loop          (:385-403, 561-830)
   feast_gbgv / feast_gbev   general              -> full-contour loop       (:1548-1600, 1088-1385)
 """
@@ -12,10 +12,9 @@ from __future__ import annotations
 
 import numpy as np
 
-from .hip_backend import feast_hip_general, feast_hip_hermitian
+from .hip_backend import feast_hip_general, feast_hip_hermitian, feast_hip_symmetric_kernel
 from .ingest import band_general_to_csr, band_upper_to_csr
 from .parameters import feastdefault, feastinit
-from .rci import HipRciServer, rci_solve_symmetric
 
 
 def _solver_keyword(solver):
@@ -35,8 +34,9 @@ def _engine(engine, device=0):
 
 def feast_sbgv(A, B, kla, klb, Emin, Emax, M0, fpm=None, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
                solver_restart=30, engine=None):
-    """Real symmetric banded generalized problem (feast_sbgv!, :9-186): the RCI kernel feast_srci! with
-    job 10/11 on the banded LU (one factorisation per contour node, cached) and job 30 on the SpMM."""
+    """Real symmetric banded generalized problem (feast_sbgv!, :9-186): the maths of the RCI kernel feast_srci! with the
+    banded LU (one factorisation per contour node, cached) -- one device sweep per refinement loop instead of a job round
+    trip per node (hip_backend.feast_hip_symmetric_kernel)."""
     fpm = feastinit() if fpm is None else fpm
     feastdefault(fpm)
     Ab, Bb = np.asarray(A, dtype=np.float64), None if B is None else np.asarray(B, dtype=np.float64)
@@ -46,10 +46,8 @@ def feast_sbgv(A, B, kla, klb, Emin, Emax, M0, fpm=None, *, solver="direct", sol
         raise ValueError("B matrix storage insufficient for klb")
     Ac = band_upper_to_csr(Ab, kla)
     Bc = None if Bb is None else band_upper_to_csr(Bb, klb)
-    tol = 10.0 ** (-int(fpm[3])) if solver_tol == 0.0 else float(solver_tol)
-    srv = HipRciServer(_engine(engine), Ac, Bc, solver=_solver_keyword(solver), rtol=tol, atol=tol if solver != "direct" else 0.0,
-                       maxit=solver_maxiter, restart=solver_restart)
-    return rci_solve_symmetric(srv, float(Emin), float(Emax), int(M0), fpm)
+    return feast_hip_symmetric_kernel(_engine(engine), Ac, Bc, float(Emin), float(Emax), int(M0), fpm, solver=_solver_keyword(solver),
+                                      solver_tol=solver_tol, solver_maxiter=solver_maxiter, solver_restart=solver_restart)
 
 
 def feast_sbev(A, ka, Emin, Emax, M0, fpm=None, **kw):

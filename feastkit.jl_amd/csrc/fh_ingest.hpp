@@ -32,8 +32,11 @@ static inline double fh_ing_add(double a, double b) { return a + b; }
 template <typename VT>
 static bool to_csr0(int64_t N, int index_base, int storage, int64_t nnz, const int64_t* ptr, const int64_t* idx,
                     const VT* val, host_csr<VT>& out) {
-    for (int64_t i = 0; i <= N; ++i)
-        if (ptr[i] - index_base < 0 || ptr[i] - index_base > nnz) return false;
+    // pointers: start at the base, never decrease, end at nnz -- overlapping ranges (ptr = {0, 5, 0, 5}) would visit more
+    // than nnz entries and run the counting transpose past its output arrays
+    if (N < 0 || nnz < 0 || ptr[0] != index_base || ptr[N] - index_base != nnz) return false;
+    for (int64_t i = 0; i < N; ++i)
+        if (ptr[i + 1] < ptr[i]) return false;
     for (int64_t k = 0; k < nnz; ++k)
         if (idx[k] - index_base < 0 || idx[k] - index_base >= N) return false;
     out.ptr.assign(N + 1, 0);

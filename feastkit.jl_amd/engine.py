@@ -143,8 +143,10 @@ class HipEngine:
     # -- problem ------------------------------------------------------------------
     @staticmethod
     def _fingerprint(M):
-        """Cheap content fingerprint of a matrix argument (shape, dtype, sums of the index and value arrays): a repeated
-        feast() call with the same matrices must not pay the ingest (union pattern, chunked rows, upload) again."""
+        """Content fingerprint of a matrix argument: shape, dtypes and a 128-bit hash over the BYTES of indptr, indices and
+        data (position dependent: a permutation of the values on the same pattern, A vs A^T of a structurally symmetric
+        matrix, two swapped entries all change it).  A repeated feast() call with the same matrices must not pay the
+        ingest (union pattern, chunked rows, upload) again; xxh3 takes 0.2 ms on cfg 3's 341 500 nonzeros."""
         import scipy.sparse as sp
         if M is None:
             return None
@@ -152,9 +154,15 @@ class HipEngine:
             M = M if sp.isspmatrix_csr(M) else None
             if M is None:
                 return False                                     # other formats: converted anyway, do not cache
-            d = M.data
-            return ("csr", M.shape, M.nnz, str(d.dtype), complex(d.sum()), float(np.abs(d).sum()), int(M.indices.sum(dtype=np.int64)),
-                    int(M.indptr.sum(dtype=np.int64)))
+            try:
+                import xxhash
+                h = xxhash.xxh3_128()
+            except ImportError:                                  # pragma: no cover - xxhash ships with the image
+                import hashlib
+                h = hashlib.blake2b(digest_size=16)
+            for a in (M.indptr, M.indices, M.data):
+                h.update(memoryview(np.ascontiguousarray(a)).cast("B"))
+            return ("csr", M.shape, M.nnz, str(M.data.dtype), str(M.indices.dtype), str(M.indptr.dtype), h.hexdigest())
         return False                                             # dense input: the upload IS the cost, no fingerprint pass
 
     def set_problem(self, A, B=None):

@@ -24,6 +24,7 @@ The reduced M0 x M0 eigenproblem stays on host LAPACK (SURVEY.md section 8 row a
 from __future__ import annotations
 
 import math
+import threading
 import time
 
 import numpy as np
@@ -49,35 +50,30 @@ except Exception:
 class small_lapack:
     """Context manager: run the enclosed host LAPACK calls on one BLAS thread.  Re-entrant and cheap when nested: only the
     outermost level talks to threadpoolctl (setting and restoring the limits costs 0.1-0.3 ms, as much as the 64 x 64
-    eigenproblem itself), so the drivers hold it for the whole solve and the per-loop calls nest inside it for free."""
+    eigenproblem itself), so the drivers hold it for the whole solve and the per-loop calls nest inside it for free.
+    The nesting depth is process wide (the BLAS limit is) and guarded by a lock: drivers running on several host threads
+    (one engine each) share one limit, released when the last of them leaves."""
     _depth = 0
     _outer = None
+    _lock = threading.Lock()
 
     def __enter__(self):
         cls = small_lapack
-        if cls._depth == 0 and _BLAS_POOLS is not None:
-            cls._outer = _BLAS_POOLS.limit(limits=1)
-            cls._outer.__enter__()
-        cls._depth += 1
-        self._entered = True
+        with cls._lock:
+            if cls._depth == 0 and _BLAS_POOLS is not None:
+                cls._outer = _BLAS_POOLS.limit(limits=1)
+                cls._outer.__enter__()
+            cls._depth += 1
         return self
 
     def __exit__(self, *exc):
         cls = small_lapack
-        if not getattr(self, "_entered", False):
-            return False
-        self._entered = False
-        cls._depth -= 1
-        if cls._depth == 0 and cls._outer is not None:
-            ctx, cls._outer = cls._outer, None
-            ctx.__exit__(*(exc if len(exc) == 3 else (None, None, None)))
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._outer is not None:
+                ctx, cls._outer = cls._outer, None
+                ctx.__exit__(None, None, None)
         return False
-
-    def __del__(self):                        # a driver that left through an exception still releases the limit
-        try:
-            self.__exit__(None, None, None)
-        except Exception:
-            pass
 
 
 def seeded_subspace(N, M0, seed=20260515, complex_values=False):
@@ -326,224 +322,224 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     ph = stats["phase_seconds"]
     tick = time.perf_counter
 
-    _blas_guard = small_lapack()
-    _blas_guard.__enter__()                  # one BLAS thread for the whole solve (released before returning)
     epsout_mp = math.inf                     # outer residual of the previous loop (refinement tolerance of complex64 factors)
     t_loops = time.perf_counter()
-    for loop_idx in range(0, maxloop + 1):
-        loop_count = loop_idx
-        t_ = tick()
-        lam_guess = ritz_lambda if (iterative and warm_start) else None
-        col_mask = None
-        if lam_guess is not None and freeze_guards_after is not None and loop_idx > freeze_guards_after:
-            # guard columns (Ritz value outside the interval) keep their warm start q/(z - lambda): they
-            # stay in the subspace, scaled by the filter value, but no solves are spent on them
-            col_mask = np.array([1 if Emin <= lam_guess[c] <= Emax else 0 for c in range(active)], dtype=np.int32)
-        if hasattr(engine, "set_column_mask"):
-            engine.set_column_mask(col_mask)                    # one-shot: consumed by the sweep below
-        if my_cgs > 1:
-            c0, c1 = column_block(active)
-            engine.set_column_block(c0, c1 - c0)
-        if inner_precision == 32 and not iterative:
-            # inexact FEAST on complex64 factors: the solves are refined only as far as the current outer residual needs
-            # (no refinement in the first loop; the last loops reach the full tolerance)
-            ref_tol = 1.0 if not math.isfinite(epsout_mp) else min(1.0, max(tol_value, 1e-2 * epsout_mp))
-            engine.set_solver(solver, rtol=ref_tol, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
-                              factor_precision=32, cache_factors=True)
-        # one call = this rank's (nodes x column block) sweep + the packed all-reduce inside the C ABI:
-        # dP and status come back summed over all ranks (status indexed by contour node when world > 1)
-        dP, status, st = engine.contour_apply(dQ, active, lam_guess)
-        if my_cgs > 1:
-            engine.set_column_block(0, -1)
-        ph["apply"] += tick() - t_
-        stats["krylov_iterations"] += st.get("krylov_iterations", 0)
-        stats["spmm_calls"] += st.get("spmm_calls", 0)
-        stats["factorizations"] += st.get("factorizations", 0)
-        stats["solve_seconds"] += st.get("seconds_solve", 0.0)
-        if hasattr(engine, "last_node_iterations"):
-            stats["node_iterations"].append([int(v) for v in engine.last_node_iterations(count)])
-            stats["node_lists"].append([int(v) for v in local_nodes])
-        local_fail = int(np.max(status)) if (world > 1 or count > 0) else 0
-        if split_layout and loop_idx >= 1 and hasattr(engine, "last_global_node_iterations"):
-            # node-only layout asked for: re-derive it from the measured iteration counts and let the heaviest nodes be
-            # split by columns over several ranks when that lowers the largest share (contour.split_balanced_assignment);
-            # the counts arrived in the tail of the packed all-reduce, summed over the ranks that swept a node
-            costs = [float(v) / node_parts.get(e, 1) for e, v in enumerate(engine.last_global_node_iterations())]
-            layout = node_assignment(costs, world) if callable(node_assignment) else split_balanced_assignment(costs, world, ncols=active)
-            nodes_here, my_cg, my_cgs = layout[rank]
-            node_parts = {e: k for nodes, _g, k in layout for e in nodes}
-            stats["layout"] = [(list(map(int, nodes)), int(g), int(k)) for nodes, g, k in layout]
-            if list(nodes_here) != list(local_nodes):
-                engine.set_node_list(nodes_here)
-                count, local_nodes = len(nodes_here), list(nodes_here)
-                stats["local_nodes"] = [int(v) for v in local_nodes]
-        elif (node_assignment == "balanced" and node_groups > 1 and iterative and hasattr(engine, "last_global_node_iterations")
-                and loop_idx >= 1):
-            # re-balance the node groups from the iteration counts the sweep just measured (they arrived in the tail of the
-            # packed all-reduce and are identical on every rank): the slow near-axis nodes no longer share a group by accident
-            nodes_here = cost_balanced_contour_points(engine.last_global_node_iterations(), node_groups)[node_rank]
-            if list(nodes_here) != list(local_nodes):
-                engine.set_node_list(nodes_here)
-                count, local_nodes = len(nodes_here), list(nodes_here)
-                stats["local_nodes"] = [int(v) for v in local_nodes]
-        if local_fail == 8 or (local_fail == 5 and not warm_start):
-            # direct: singular shift -> info 8 (src/dense/feast_dense.jl:199-203);
-            # reference GMRES failure -> info 5 (src/dense/feast_dense.jl:221-225)
-            info = int(FeastError.Feast_ERROR_LAPACK if local_fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE)
-            break
-
-        t_ = tick()
-        rank_q = engine.orthonormalize(dP, active, SQRT_EPS)       # _feast_qr_compress!
-        ph["ortho"] += tick() - t_
-        if rank_q == 0:
-            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
-            break
-        if reduced_solver == "device" and rank_q <= 64 and trace is None and hasattr(engine, "rayleigh_ritz"):
-            # project + reduced eigenproblem (Jacobi in LDS) + reorder + Ritz vectors + residuals in one call;
-            # None: reduced B not positive definite -> the host path below (general fallback of the reference)
+    # one BLAS thread for the whole solve; the `with` releases the process-wide limit on every way out, including an
+    # exception from the engine inside the loop (FeastHipError, a poisoned handle)
+    with small_lapack():
+        for loop_idx in range(0, maxloop + 1):
+            loop_count = loop_idx
             t_ = tick()
-            rr = engine.rayleigh_ritz(dP, rank_q, Emin, Emax, use_B=True)
-            ph["ritz"] += tick() - t_
-            if rr is not None:
-                dX, lam_sorted, M, res = rr
-                if M == 0 and not (iterative and warm_start):
-                    info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
-                    break
-                lam_vec[:rank_q] = lam_sorted
-                if M > 0:
-                    res_vec[:M] = res
-                    epsout = float(res.max())
+            lam_guess = ritz_lambda if (iterative and warm_start) else None
+            col_mask = None
+            if lam_guess is not None and freeze_guards_after is not None and loop_idx > freeze_guards_after:
+                # guard columns (Ritz value outside the interval) keep their warm start q/(z - lambda): they
+                # stay in the subspace, scaled by the filter value, but no solves are spent on them
+                col_mask = np.array([1 if Emin <= lam_guess[c] <= Emax else 0 for c in range(active)], dtype=np.int32)
+            if hasattr(engine, "set_column_mask"):
+                engine.set_column_mask(col_mask)                    # one-shot: consumed by the sweep below
+            if my_cgs > 1:
+                c0, c1 = column_block(active)
+                engine.set_column_block(c0, c1 - c0)
+            if inner_precision == 32 and not iterative:
+                # inexact FEAST on complex64 factors: the solves are refined only as far as the current outer residual needs
+                # (no refinement in the first loop; the last loops reach the full tolerance)
+                ref_tol = 1.0 if not math.isfinite(epsout_mp) else min(1.0, max(tol_value, 1e-2 * epsout_mp))
+                engine.set_solver(solver, rtol=ref_tol, atol=0.0, maxit=solver_maxiter, restart=solver_restart,
+                                  factor_precision=32, cache_factors=True)
+            # one call = this rank's (nodes x column block) sweep + the packed all-reduce inside the C ABI:
+            # dP and status come back summed over all ranks (status indexed by contour node when world > 1)
+            dP, status, st = engine.contour_apply(dQ, active, lam_guess)
+            if my_cgs > 1:
+                engine.set_column_block(0, -1)
+            ph["apply"] += tick() - t_
+            stats["krylov_iterations"] += st.get("krylov_iterations", 0)
+            stats["spmm_calls"] += st.get("spmm_calls", 0)
+            stats["factorizations"] += st.get("factorizations", 0)
+            stats["solve_seconds"] += st.get("seconds_solve", 0.0)
+            if hasattr(engine, "last_node_iterations"):
+                stats["node_iterations"].append([int(v) for v in engine.last_node_iterations(count)])
+                stats["node_lists"].append([int(v) for v in local_nodes])
+            local_fail = int(np.max(status)) if (world > 1 or count > 0) else 0
+            if split_layout and loop_idx >= 1 and hasattr(engine, "last_global_node_iterations"):
+                # node-only layout asked for: re-derive it from the measured iteration counts and let the heaviest nodes be
+                # split by columns over several ranks when that lowers the largest share (contour.split_balanced_assignment);
+                # the counts arrived in the tail of the packed all-reduce, summed over the ranks that swept a node
+                costs = [float(v) / node_parts.get(e, 1) for e, v in enumerate(engine.last_global_node_iterations())]
+                layout = node_assignment(costs, world) if callable(node_assignment) else split_balanced_assignment(costs, world, ncols=active)
+                nodes_here, my_cg, my_cgs = layout[rank]
+                node_parts = {e: k for nodes, _g, k in layout for e in nodes}
+                stats["layout"] = [(list(map(int, nodes)), int(g), int(k)) for nodes, g, k in layout]
+                if list(nodes_here) != list(local_nodes):
+                    engine.set_node_list(nodes_here)
+                    count, local_nodes = len(nodes_here), list(nodes_here)
+                    stats["local_nodes"] = [int(v) for v in local_nodes]
+            elif (node_assignment == "balanced" and node_groups > 1 and iterative and hasattr(engine, "last_global_node_iterations")
+                    and loop_idx >= 1):
+                # re-balance the node groups from the iteration counts the sweep just measured (they arrived in the tail of the
+                # packed all-reduce and are identical on every rank): the slow near-axis nodes no longer share a group by accident
+                nodes_here = cost_balanced_contour_points(engine.last_global_node_iterations(), node_groups)[node_rank]
+                if list(nodes_here) != list(local_nodes):
+                    engine.set_node_list(nodes_here)
+                    count, local_nodes = len(nodes_here), list(nodes_here)
+                    stats["local_nodes"] = [int(v) for v in local_nodes]
+            if local_fail == 8 or (local_fail == 5 and not warm_start):
+                # direct: singular shift -> info 8 (src/dense/feast_dense.jl:199-203);
+                # reference GMRES failure -> info 5 (src/dense/feast_dense.jl:221-225)
+                info = int(FeastError.Feast_ERROR_LAPACK if local_fail == 8 else FeastError.Feast_ERROR_NO_CONVERGENCE)
+                break
+
+            t_ = tick()
+            rank_q = engine.orthonormalize(dP, active, SQRT_EPS)       # _feast_qr_compress!
+            ph["ortho"] += tick() - t_
+            if rank_q == 0:
+                info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                break
+            if reduced_solver == "device" and rank_q <= 64 and trace is None and hasattr(engine, "rayleigh_ritz"):
+                # project + reduced eigenproblem (Jacobi in LDS) + reorder + Ritz vectors + residuals in one call;
+                # None: reduced B not positive definite -> the host path below (general fallback of the reference)
+                t_ = tick()
+                rr = engine.rayleigh_ritz(dP, rank_q, Emin, Emax, use_B=True)
+                ph["ritz"] += tick() - t_
+                if rr is not None:
+                    dX, lam_sorted, M, res = rr
+                    if M == 0 and not (iterative and warm_start):
+                        info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                        break
+                    lam_vec[:rank_q] = lam_sorted
+                    if M > 0:
+                        res_vec[:M] = res
+                        epsout = float(res.max())
+                    else:
+                        epsout = math.inf
+                    epsout_mp = epsout
+                    M_found = M
+                    stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout,
+                                           "krylov_iterations": st.get("krylov_iterations", 0)})
+                    if M > 0 and epsout <= eps_tol:
+                        break
+                    if loop_idx == maxloop:
+                        info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                        break
+                    active = rank_q
+                    dQ = dX
+                    ritz_lambda = lam_sorted.copy()
+                    continue
+            t_ = tick()
+            Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
+            ph["project"] += tick() - t_
+            t_ = tick()
+            try:
+                lam_red, v_red = _reduced_hermitian_eig(Sq, Aq)
+            except Exception:
+                info = int(FeastError.Feast_ERROR_LAPACK)
+                break
+            ph["eig"] += tick() - t_
+            perm, M = _reorder_by_interval(lam_red, Emin, Emax, rank_q)
+            lam_sorted = lam_red[perm]
+            V_sorted = np.asfortranarray(v_red[:, perm])
+            if trace is not None:
+                trace.append({"loop": loop_idx, "rank": rank_q, "M": M, "lambda": lam_sorted.copy(), "status": status.copy(),
+                              "stats": dict(st),
+                              "node_iterations": engine.last_node_iterations(count) if hasattr(engine, "last_node_iterations") else None,
+                              "column_iterations": engine.last_column_iterations(count, active) if hasattr(engine, "last_column_iterations") else None})
+            if M == 0 and not (iterative and warm_start):
+                info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                break
+            t_ = tick()
+            dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+            n_spurious = 0
+            if inexact and spurious_filter and loop_idx >= 1 and M > 1:
+                # Inexact inner solves leave solver noise in the guard columns.  Its Ritz values are arbitrary; one that
+                # lands inside the interval has an O(1) residual that never contracts and would hold epsout up forever
+                # (variant A has no spurious-pair removal; with exact solves the guard columns are true eigen-directions
+                # and stay outside).  A pair is set aside when its relative residual is > 0.1 AND > 100x the smallest
+                # residual of the pairs inside: a true pair inside the interval sees a filter value >= 1/2 and contracts
+                # with the others, it cannot sit at 10 % while another pair is 100x ahead.  Set-aside pairs stay in the
+                # subspace and are re-examined every loop (measured on a random pencil: the ten true pairs contract by
+                # ~1e-2 per loop while one to three noise pairs stay at residual 1).
+                flag = (res > 0.1) & (res > 100.0 * float(res.min()))
+                n_spurious = int(flag.sum())
+                if 0 < n_spurious < M:
+                    order = np.concatenate([np.nonzero(~flag)[0], np.nonzero(flag)[0], np.arange(M, rank_q)])
+                    lam_sorted = lam_sorted[order]
+                    V_sorted = np.asfortranarray(V_sorted[:, order])
+                    M = M - n_spurious
+                    dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
                 else:
-                    epsout = math.inf
-                epsout_mp = epsout
-                M_found = M
-                stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout,
-                                       "krylov_iterations": st.get("krylov_iterations", 0)})
-                if M > 0 and epsout <= eps_tol:
-                    break
-                if loop_idx == maxloop:
-                    info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
-                    break
-                active = rank_q
-                dQ = dX
-                ritz_lambda = lam_sorted.copy()
-                continue
-        t_ = tick()
-        Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
-        ph["project"] += tick() - t_
-        t_ = tick()
-        try:
-            lam_red, v_red = _reduced_hermitian_eig(Sq, Aq)
-        except Exception:
-            info = int(FeastError.Feast_ERROR_LAPACK)
-            break
-        ph["eig"] += tick() - t_
-        perm, M = _reorder_by_interval(lam_red, Emin, Emax, rank_q)
-        lam_sorted = lam_red[perm]
-        V_sorted = np.asfortranarray(v_red[:, perm])
-        if trace is not None:
-            trace.append({"loop": loop_idx, "rank": rank_q, "M": M, "lambda": lam_sorted.copy(), "status": status.copy(),
-                          "stats": dict(st),
-                          "node_iterations": engine.last_node_iterations(count) if hasattr(engine, "last_node_iterations") else None,
-                          "column_iterations": engine.last_column_iterations(count, active) if hasattr(engine, "last_column_iterations") else None})
-        if M == 0 and not (iterative and warm_start):
-            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
-            break
-        t_ = tick()
-        dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
-        n_spurious = 0
-        if inexact and spurious_filter and loop_idx >= 1 and M > 1:
-            # Inexact inner solves leave solver noise in the guard columns.  Its Ritz values are arbitrary; one that
-            # lands inside the interval has an O(1) residual that never contracts and would hold epsout up forever
-            # (variant A has no spurious-pair removal; with exact solves the guard columns are true eigen-directions
-            # and stay outside).  A pair is set aside when its relative residual is > 0.1 AND > 100x the smallest
-            # residual of the pairs inside: a true pair inside the interval sees a filter value >= 1/2 and contracts
-            # with the others, it cannot sit at 10 % while another pair is 100x ahead.  Set-aside pairs stay in the
-            # subspace and are re-examined every loop (measured on a random pencil: the ten true pairs contract by
-            # ~1e-2 per loop while one to three noise pairs stay at residual 1).
-            flag = (res > 0.1) & (res > 100.0 * float(res.min()))
-            n_spurious = int(flag.sum())
-            if 0 < n_spurious < M:
-                order = np.concatenate([np.nonzero(~flag)[0], np.nonzero(flag)[0], np.arange(M, rank_q)])
-                lam_sorted = lam_sorted[order]
-                V_sorted = np.asfortranarray(V_sorted[:, order])
-                M = M - n_spurious
-                dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+                    n_spurious = 0
+            ph["ritz"] += tick() - t_
+            lam_vec[:rank_q] = lam_sorted
+            if M > 0:
+                res_vec[:M] = res
+                epsout = float(res.max())
             else:
-                n_spurious = 0
-        ph["ritz"] += tick() - t_
-        lam_vec[:rank_q] = lam_sorted
-        if M > 0:
-            res_vec[:M] = res
-            epsout = float(res.max())
-        else:
-            epsout = math.inf
-        epsout_mp = epsout
-        M_found = M
-        stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout, "set_aside": n_spurious,
-                               "krylov_iterations": st.get("krylov_iterations", 0),
-                               "res_inside": np.array(res[:M], dtype=float).copy() if M > 0 else np.zeros(0)})
-        if M > 0 and epsout <= eps_tol:
-            break
-        if loop_idx == maxloop:
-            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
-            break
-        if abort_check is not None and world == 1 and abort_check(loop_idx, [l["epsout"] for l in stats["loops"]],
-                                                                  time.perf_counter() - t_loops):
-            # the caller has a cheaper way to finish (api.feast: the sparse direct solver): stop here
-            info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
-            stats["aborted"] = True
-            break
-        if inexact:
-            # stagnation guard: the outer residual should contract by about inner_rtol per loop.  When it has not even
-            # halved over two loops the inner solves are not delivering (iteration cap too low for this matrix):
-            # double the cap (cfg 3 contracts by 0.03-0.1 per loop and never gets here)
-            eps_hist.append(epsout)
-            if len(eps_hist) >= 3 and eps_hist[-1] > 0.5 * eps_hist[-3] and inner_cap < 16 * solver_maxiter:
-                inner_cap *= 2
-                engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
-                                  factor_precision=inner_precision)
-                stats["inner_cap"] = inner_cap
-                eps_hist.clear()
-        if auto_contour:
-            # Safeguard first.  The policy promised a contraction of max(filter ratio, inner_rtol) < 0.5 per loop.  When a
-            # loop delivers less than 0.3 there are two possible culprits: inner solves that stopped at the iteration
-            # cap before reaching inner_rtol (status 5 on some node: a taller ellipse would only HELP them -- raise the
-            # cap instead), or a filter that is too soft for this spectrum (lower the ellipse, down to the circle).
-            prev = stats["loops"][-2]["epsout"] if len(stats["loops"]) >= 2 else math.inf
-            if math.isfinite(prev) and math.isfinite(epsout) and epsout > 0.3 * prev:
-                if int(np.max(status)) == 5 and inner_cap < 16 * solver_maxiter:
+                epsout = math.inf
+            epsout_mp = epsout
+            M_found = M
+            stats["loops"].append({"loop": loop_idx, "rank": rank_q, "M": M, "epsout": epsout, "set_aside": n_spurious,
+                                   "krylov_iterations": st.get("krylov_iterations", 0),
+                                   "res_inside": np.array(res[:M], dtype=float).copy() if M > 0 else np.zeros(0)})
+            if M > 0 and epsout <= eps_tol:
+                break
+            if loop_idx == maxloop:
+                info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                break
+            if abort_check is not None and world == 1 and abort_check(loop_idx, [l["epsout"] for l in stats["loops"]],
+                                                                      time.perf_counter() - t_loops):
+                # the caller has a cheaper way to finish (api.feast: the sparse direct solver): stop here
+                info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
+                stats["aborted"] = True
+                break
+            if inexact:
+                # stagnation guard: the outer residual should contract by about inner_rtol per loop.  When it has not even
+                # halved over two loops the inner solves are not delivering (iteration cap too low for this matrix):
+                # double the cap (cfg 3 contracts by 0.03-0.1 per loop and never gets here)
+                eps_hist.append(epsout)
+                if len(eps_hist) >= 3 and eps_hist[-1] > 0.5 * eps_hist[-3] and inner_cap < 16 * solver_maxiter:
                     inner_cap *= 2
                     engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
                                       factor_precision=inner_precision)
                     stats["inner_cap"] = inner_cap
                     eps_hist.clear()
-                elif policy["aspect"] > 100:
-                    policy["cap"] = max(100, policy["aspect"] // 2)
-            # Steering: the filter model evaluated at the reach of the subspace.  The guard Ritz values overshoot outward
-            # while they are far from converged (measured on four 50 000-unknown pencils: apparent reach 5-15 half widths
-            # after loop 0, 2-4 while the wanted pairs pass 1e-3, within 2 % of the first eigenvalue outside the subspace
-            # late), hence a cautious quantile of their distances early, nearly the outermost one later, and never more
-            # than double the ratio in one loop.  Five steering rules were measured on those pencils (this one; the same
-            # gated on epsout < 1e-2; outermost guard with one notch per loop; acting only on a reach that two loops
-            # agree on; a feedback rule on the observed contraction): all land within 10 % of each other and 3-9 times
-            # ahead of the circle -- the early over-estimates cost little because an early loop on a taller ellipse is
-            # also a cheaper loop; this rule had the best geometric mean.
-            reach = subspace_reach(lam_sorted[:rank_q], Emin, Emax, 0.8 if not (epsout < 1e-2) else 0.95) if M > 0 else None
-            want = (policy_pick(reach, lam_sorted[:M], limit=2 * policy["aspect"]) if reach is not None
-                    else min(policy["aspect"], policy["cap"]))
-            if want != policy["aspect"]:
-                fpm[18] = policy["aspect"] = want
-                Zne, Wne = feast_contour(Emin, Emax, fpm)
-                engine.set_contour(Zne, Wne, 2.0)
-                engine.set_node_list(local_nodes)
-            policy["history"].append(policy["aspect"])
-            policy.setdefault("reach", []).append(None if reach is None else round(reach, 3))
-        active = rank_q
-        dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
-        ritz_lambda = lam_sorted.copy()
+            if auto_contour:
+                # Safeguard first.  The policy promised a contraction of max(filter ratio, inner_rtol) < 0.5 per loop.  When a
+                # loop delivers less than 0.3 there are two possible culprits: inner solves that stopped at the iteration
+                # cap before reaching inner_rtol (status 5 on some node: a taller ellipse would only HELP them -- raise the
+                # cap instead), or a filter that is too soft for this spectrum (lower the ellipse, down to the circle).
+                prev = stats["loops"][-2]["epsout"] if len(stats["loops"]) >= 2 else math.inf
+                if math.isfinite(prev) and math.isfinite(epsout) and epsout > 0.3 * prev:
+                    if int(np.max(status)) == 5 and inner_cap < 16 * solver_maxiter:
+                        inner_cap *= 2
+                        engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
+                                          factor_precision=inner_precision)
+                        stats["inner_cap"] = inner_cap
+                        eps_hist.clear()
+                    elif policy["aspect"] > 100:
+                        policy["cap"] = max(100, policy["aspect"] // 2)
+                # Steering: the filter model evaluated at the reach of the subspace.  The guard Ritz values overshoot outward
+                # while they are far from converged (measured on four 50 000-unknown pencils: apparent reach 5-15 half widths
+                # after loop 0, 2-4 while the wanted pairs pass 1e-3, within 2 % of the first eigenvalue outside the subspace
+                # late), hence a cautious quantile of their distances early, nearly the outermost one later, and never more
+                # than double the ratio in one loop.  Five steering rules were measured on those pencils (this one; the same
+                # gated on epsout < 1e-2; outermost guard with one notch per loop; acting only on a reach that two loops
+                # agree on; a feedback rule on the observed contraction): all land within 10 % of each other and 3-9 times
+                # ahead of the circle -- the early over-estimates cost little because an early loop on a taller ellipse is
+                # also a cheaper loop; this rule had the best geometric mean.
+                reach = subspace_reach(lam_sorted[:rank_q], Emin, Emax, 0.8 if not (epsout < 1e-2) else 0.95) if M > 0 else None
+                want = (policy_pick(reach, lam_sorted[:M], limit=2 * policy["aspect"]) if reach is not None
+                        else min(policy["aspect"], policy["cap"]))
+                if want != policy["aspect"]:
+                    fpm[18] = policy["aspect"] = want
+                    Zne, Wne = feast_contour(Emin, Emax, fpm)
+                    engine.set_contour(Zne, Wne, 2.0)
+                    engine.set_node_list(local_nodes)
+                policy["history"].append(policy["aspect"])
+                policy.setdefault("reach", []).append(None if reach is None else round(reach, 3))
+            active = rank_q
+            dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
+            ritz_lambda = lam_sorted.copy()
 
-    _blas_guard.__exit__(None, None, None)
     if auto_contour:
         stats["contour_policy"] = {"fpm18_per_loop": policy["history"], "cap": policy["cap"], "reach": policy.get("reach")}
     if hasattr(engine, "set_column_mask"):
@@ -801,6 +797,80 @@ def pfeast_hip_moments(engine, A, B, Emin, Emax, M0, fpm, *, group=None, Q0=None
     M = int(sum(1 for i in range(M0) if Emin <= lam[i] <= Emax))
     return FeastResult(lam[:M].copy(), q[:, :M].copy(), M, res[:M].copy(), int(FeastError.Feast_ERROR_NO_CONVERGENCE),
                        float(res[:M].max()) if M else 0.0, max_loops)
+
+
+def feast_hip_symmetric_kernel(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,
+                               solver_restart=30, group=None, Q0=None, seed=20260515, contour=None):
+    """What the real-symmetric RCI kernel ``feast_srci!`` (src/kernel/feast_kernel.jl:7-275) returns when its jobs are
+    served -- the maths behind ``feast_sbgv!`` (src/banded/feast_banded.jl:87-175) -- as ONE device sweep per refinement
+    loop instead of a FACTORIZE / SOLVE round trip per quadrature node: ``contour_apply(want_moments)`` yields
+        Q_proj = Re sum_e 2 w_e Y_e,  Aq = Re sum_e 2 w_e Q^T Y_e,  Sq = Re sum_e 2 w_e z_e Q^T Y_e   (:146-169)
+    summed over the ranks; then, as the kernel does: ``eigen(Sq, Aq)`` of the general reduced pencil (:175) with LAPACK's
+    eigenvector scaling (the residuals below are taken on un-normalised Ritz vectors and depend on it), q = Q_proj Re(V)
+    with no normalisation (:183-187), stable inside-first reorder (:189-215), residual ||A q - lambda q|| / max(|lambda|, 1)
+    WITHOUT B (:244-252: generalized problems therefore run all fpm[4] loops and return info = 0), stop test with
+    loop >= fpm[4] (:258), all M0 Ritz vectors carried to the next loop (:269), feast_sort! at the end."""
+    import scipy.sparse as _sp
+    N = A.shape[0]
+    feastdefault(fpm)
+    info = check_feast_srci_input(N, M0, Emin, Emax)
+    if info:
+        return FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), info, 0.0, 0)
+    rank, world = _world(engine, group)
+    engine.set_problem(A, B)
+    Zne, Wne = feast_contour(Emin, Emax, fpm) if contour is None else contour
+    engine.set_contour(Zne, Wne, 2.0)                     # weight = 2 * Wne[e], feast_kernel.jl:150
+    engine.set_real_projection(True)                      # real(...) after the sweep, :166-169
+    first, count = distribute_contour_points(len(Zne), world)[rank]
+    engine.set_node_range(first, count)
+    iterative = solver not in ("direct", "lu", "banded")
+    tol_value = feast_tolerance(fpm) if solver_tol == 0.0 else float(solver_tol)
+    engine.set_solver(solver, rtol=tol_value, atol=tol_value if iterative else 0.0, maxit=solver_maxiter,
+                      restart=solver_restart, cache_factors=True)
+    if Q0 is not None:                                    # fpm[5] = 1: the caller's columns, normalised (:68-80)
+        work = np.array(np.real(Q0), dtype=np.float64)
+        nrm = np.linalg.norm(work, axis=0)
+        nrm[nrm == 0] = 1.0
+        work = work / nrm
+    else:
+        work = np.real(seeded_subspace(N, M0, seed))
+    eps_tol = feast_tolerance(fpm)
+    maxloop = int(fpm[4])
+    stats = {"krylov_iterations": 0, "factorizations": 0, "solve_seconds": 0.0}
+    empty = lambda code, loop: FeastResult(np.zeros(0), np.zeros((N, 0)), 0, np.zeros(0), int(code), 0.0, loop, stats)
+    loop = 0
+    with small_lapack():
+        while True:
+            dQ = engine.upload(work)
+            dP, status, st, Aq, Sq = engine.contour_apply(dQ, M0, None, want_moments=True)
+            for k_, s_ in (("krylov_iterations", "krylov_iterations"), ("factorizations", "factorizations"), ("solve_seconds", "seconds_solve")):
+                stats[k_] += st.get(s_, 0)
+            if (int(np.max(status)) if (world > 1 or count > 0) else 0) != 0:
+                return empty(FeastError.Feast_ERROR_LAPACK, loop)           # a failed SOLVE job, feast_banded.jl:137-147
+            try:
+                w, V = sla.eig(np.real(Sq), np.real(Aq))
+            except Exception:
+                return empty(FeastError.Feast_ERROR_LAPACK, loop)
+            V = np.array(V, copy=True)
+            for j in range(V.shape[1]):                                     # LAPACK ggev scaling: max |re| + |im| = 1
+                s_ = np.max(np.abs(V[:, j].real) + np.abs(V[:, j].imag))
+                if s_ > 0:
+                    V[:, j] /= s_
+            lam = np.real(w)
+            perm, M = _reorder_by_interval(lam, Emin, Emax, M0)
+            if M == 0:
+                return empty(FeastError.Feast_ERROR_NO_CONVERGENCE, loop)
+            lam = lam[perm]
+            Vp = np.asfortranarray(np.real(V)[:, perm].astype(np.complex128))
+            # q = Q_proj Re(V) for all M0 columns, residuals of the first M without B and without normalisation
+            dX, res = engine.ritz_residual(dP, M0, Vp, lam, M, normalize=False, use_B=False)
+            epsout = float(res.max())
+            if epsout <= eps_tol or loop >= maxloop:
+                X = np.real(engine.download(dX[:M], M))
+                order = np.argsort(lam[:M], kind="stable")                  # feast_sort!
+                return FeastResult(lam[:M][order].copy(), X[:, order].copy(), M, res[order].copy(), 0, epsout, loop, stats)
+            loop += 1
+            work = np.real(engine.download(dX, M0))
 
 
 def pfeast_hip_hermitian_moments(engine, A, B, Emin, Emax, M0, fpm, *, solver="direct", solver_tol=0.0, solver_maxiter=500,

@@ -190,12 +190,51 @@ static void one_case(std::mt19937_64& rng, bool real_chunks) {
         bad.ptr[0] = base - 1;
         CHECK(fh_prepare_csr<VT>(N, base, storage, (int64_t)bad.idx.size(), bad.ptr.data(), bad.idx.data(), bad.val.data(), 0, nullptr,
                                  nullptr, nullptr, 0, R, EXT, real_chunks, Q, err) == 1);
+        // non-monotone pointers with every value in range: an interior pointer pushed past its successor (overlapping
+        // ranges visit more than nnz entries), in both storages
+        if (N >= 3) {
+            bad = A;
+            const int i = 1 + (int)(u(rng) * (N - 2));                   // 1 .. N-2
+            bad.ptr[i] = bad.ptr[i + 1] + 1 + (int64_t)(u(rng) * 3);
+            if (bad.ptr[i] - base <= (int64_t)bad.idx.size())
+                CHECK(fh_prepare_csr<VT>(N, base, storage, (int64_t)bad.idx.size(), bad.ptr.data(), bad.idx.data(), bad.val.data(), 0,
+                                         nullptr, nullptr, nullptr, 0, R, EXT, real_chunks, Q, err) == 1);
+        }
+        // the same defect in B only
+        if (hasB && N >= 3 && !B.idx.empty()) {
+            input<VT> badB = B;
+            badB.ptr[1] = (int64_t)badB.idx.size() + base;
+            badB.ptr[2] = base;
+            CHECK(fh_prepare_csr<VT>(N, base, storage, (int64_t)A.idx.size(), A.ptr.data(), A.idx.data(), A.val.data(),
+                                     (int64_t)badB.idx.size(), badB.ptr.data(), badB.idx.data(), badB.val.data(), 0, R, EXT,
+                                     real_chunks, Q, err) == 2);
+        }
     }
+}
+
+// The advisor's case (round 3): N = 3, nnz = 5, ptr = {0, 5, 0, 5}, every index 2 -- all values in range, the column
+// ranges overlap, and the CSC counting transpose wrote fill[r]++ past out.idx / out.val (ASan: heap-buffer-overflow).
+static void overlapping_ranges_case() {
+    for (int storage = 0; storage < 2; ++storage)
+        for (int base = 0; base < 2; ++base) {
+            std::vector<int64_t> ptr = {0 + base, 5 + base, 0 + base, 5 + base}, idx(5, 2 + base);
+            std::vector<double> val(5, 1.0);
+            fh_prepared<double> Q;
+            std::string err;
+            CHECK(fh_prepare_csr<double>(3, base, storage, 5, ptr.data(), idx.data(), val.data(), 0, nullptr, nullptr, nullptr, 0, 16,
+                                         12, true, Q, err) == 1);
+            // as B beside a well-formed A
+            std::vector<int64_t> pa = {0 + base, 1 + base, 2 + base, 3 + base}, ia = {0 + base, 1 + base, 2 + base};
+            std::vector<double> va(3, 2.0);
+            CHECK(fh_prepare_csr<double>(3, base, storage, 3, pa.data(), ia.data(), va.data(), 5, ptr.data(), idx.data(), val.data(), 0,
+                                         16, 12, true, Q, err) == 2);
+        }
 }
 
 int main(int argc, char** argv) {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 300;
     std::mt19937_64 rng(argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 20260515ull);
+    overlapping_ranges_case();
     for (g_case = 0; g_case < cases; ++g_case) {
         if (g_case & 1) one_case<double>(rng, true);
         else one_case<c2>(rng, false);

@@ -60,6 +60,10 @@ class OracleEngine:
     def set_solver(self, solver="direct", **kw):
         self.solver = solver
 
+    def free_factors(self):
+        self.factors = {}
+        self.calls["free_factors"] = self.calls.get("free_factors", 0) + 1
+
     def empty(self, m):
         return torch.zeros((m, self.N), dtype=torch.complex128)
 

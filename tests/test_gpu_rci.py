@@ -8,7 +8,7 @@ import scipy.sparse as sp
 
 import feast_oracle as fo
 import feastkit_jl_amd as fk
-from feastkit_jl_amd import rci
+import rci_callers as rci          # the job state machines and caller loops are test infrastructure (tests/rci_callers.py)
 
 pytestmark = pytest.mark.gpu
 

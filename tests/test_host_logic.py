@@ -524,3 +524,70 @@ def test_contour_policy_driver_host_logic():
                contour=fk.feast_contour(0.0, 0.8, keep))):
         r2 = fk.feast_hip_hermitian(OracleEngine(), A, B, 0.0, 0.8, 24, keep.copy(), contour_policy="auto", **kw)
         assert r2.info == 0 and r2.M == len(inside) and "contour_policy" not in r2.stats
+
+
+def test_problem_fingerprint_is_position_dependent():
+    """the fingerprint that lets set_problem() skip a re-ingest was a tuple of SUMS, so any permutation of
+    values on one pattern collided and a reused engine silently solved the previous matrix.  It is a hash over the bytes of
+    indptr / indices / data now; the three collisions the advisor reproduced must differ."""
+    fp = fk.HipEngine._fingerprint
+    # (i) A vs A^T for a structurally symmetric, non-symmetric convection-diffusion stencil (left eigenvectors of feast_general)
+    n = 12
+    A = sp.diags([-1.3 * np.ones(n - 1), 2.0 * np.ones(n), -0.7 * np.ones(n - 1)], [-1, 0, 1], format="csr")
+    At = sp.csr_matrix(A.T)
+    assert (A != At).nnz > 0 and np.array_equal(A.indices, At.indices) and np.array_equal(A.indptr, At.indptr)
+    assert fp(A) != fp(At)
+    # (ii) a tridiagonal Hamiltonian with two on-site energies swapped
+    d = np.linspace(1.0, 2.0, n)
+    H1 = sp.diags([-np.ones(n - 1), d, -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    d2 = d.copy(); d2[[3, 7]] = d2[[7, 3]]
+    H2 = sp.diags([-np.ones(n - 1), d2, -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    assert fp(H1) != fp(H2)
+    # (iii) binary alloy: two sites of a 0/1 potential swapped (same multiset of values, same pattern)
+    v = np.array([0, 1] * (n // 2), dtype=float)
+    v2 = v.copy(); v2[[0, 1]] = v2[[1, 0]]
+    P1 = sp.diags([-np.ones(n - 1), 2 + v, -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    P2 = sp.diags([-np.ones(n - 1), 2 + v2, -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    assert fp(P1) != fp(P2)
+    # equal content -> equal fingerprint (a copy, not the same object); None and non-CSR input keep their sentinels
+    assert fp(A) == fp(A.copy()) and fp(None) is None and fp(A.tocsc()) is False and fp(A.toarray()) is False
+
+
+def test_symmetric_kernel_sweeps_equal_oracle_rci():
+    """feast_sbgv's driver (hip_backend.feast_hip_symmetric_kernel: one want_moments sweep per loop) against the oracle's
+    restatement of what feast_srci! returns when its jobs are served (fo.rci_symmetric): standard and generalized."""
+    n = 30
+    S = tridiag(n)
+    for Bm in (None, np.diag(np.linspace(1.0, 1.6, n))):
+        fpm = fk.feastinit(); fpm[2] = 8; fpm[3] = 11; fpm[4] = 6
+        got = fk.feast_hip_symmetric_kernel(OracleEngine(), S, Bm, 0.2, 1.3, 8, fpm)
+        want = fo.rci_symmetric(S, Bm, 0.2, 1.3, 8, ne=8, fpm3=11, fpm4=6)
+        assert (got.info, got.M, got.loop) == (want.info, want.M, want.loop)
+        assert np.allclose(got.lambda_, want.lam, atol=1e-11) and np.allclose(got.res, want.res, rtol=1e-6, atol=1e-13)
+        for j in range(got.M):
+            assert min(np.linalg.norm(got.q[:, j] - want.q[:, j]), np.linalg.norm(got.q[:, j] + want.q[:, j])) <= 1e-8 * np.linalg.norm(want.q[:, j])
+
+
+def test_direct_factors_are_released_when_the_call_returns():
+    """band-LU factors outlived the call that made them (40 GB on cfg 3).  feast()/feast_general() release them on
+    return unless keep_factors=True."""
+    A = sp.csr_matrix(tridiag(24))
+    for keep, want in ((False, 1), (True, 0)):
+        eng = OracleEngine()
+        r = fk.feast(A, None, (0.2, 1.3), M0=10, engine=eng, keep_factors=keep, real_projection=True)
+        assert r.info == 0 and eng.calls.get("free_factors", 0) == want
+        eng = OracleEngine()
+        g = fk.feast_general(A.astype(complex), None, 0.8, 0.5, M0=8, engine=eng, keep_factors=keep)
+        assert g.info == 0 and eng.calls.get("free_factors", 0) == want
+
+
+def test_blas_limit_released_when_the_engine_raises():
+    """an exception from the engine inside the refinement loop left the process-wide BLAS limit at one thread."""
+    from feastkit_jl_amd.hip_backend import small_lapack
+
+    class Boom(OracleEngine):
+        def orthonormalize(self, *a, **k):
+            raise fk.FeastHipError(7, "poisoned")
+    with pytest.raises(fk.FeastHipError):
+        fk.feast_hip_hermitian(Boom(), tridiag(20), None, 0.2, 1.3, 8, fk.feastinit())
+    assert small_lapack._depth == 0 and small_lapack._outer is None

@@ -1,4 +1,4 @@
-"""CPU tests of the RCI surface (feastkit.jl_amd/rci.py): the job protocol of
+"""CPU tests of the RCI job protocol (tests/rci_callers.py, the caller side the reference keeps in Julia): the job protocol of
 feast_srci!/hrci!/grci! (src/kernel/feast_kernel.jl) driven with a test-only exact job server,
 against the oracle's straight-line restatement and the reference's own RCI fixtures."""
 import numpy as np
@@ -7,7 +7,7 @@ import scipy.sparse as sp
 
 import feast_oracle as fo
 import feastkit_jl_amd as fk
-from feastkit_jl_amd import rci
+import rci_callers as rci          # the job state machines and caller loops are test infrastructure (tests/rci_callers.py)
 from rci_numpy_server import NumpyRciServer
 
 
