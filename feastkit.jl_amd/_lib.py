@@ -52,6 +52,11 @@ SYMBOLS = {
     "feasthip_rayleigh_ritz_dev": (_i, [_vp, _i64, _vp, _d, _d, _i, _vp, _vp, _vp, _vp]),
     "feasthip_contour_apply": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
     "feasthip_contour_apply_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _ps]),
+    "feasthip_contour_apply_resident": (_i, [_vp, _i64, _vp, _vp, _vp, _ps]),
+    "feasthip_rr_reduce_resident": (_i, [_vp, _i64, _d, _i, _pi, _vp, _vp]),
+    "feasthip_rr_ritz_resident": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _vp]),
+    "feasthip_resident_export": (_i, [_vp, _i, _i64, _vp]),
+    "feasthip_resident_import": (_i, [_vp, _i, _i64, _vp]),
     "feasthip_orthonormalize": (_i, [_vp, _i64, _vp, _d, _pi]),
     "feasthip_orthonormalize_dev": (_i, [_vp, _i64, _vp, _d, _pi]),
     "feasthip_project": (_i, [_vp, _i64, _vp, _i, _i, _vp, _vp]),

@@ -162,6 +162,8 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     if (hipSetDevice(device_id) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return FEASTHIP_ERROR_INTERNAL; }
     h->stream = h->own_stream;
+    if (hipHostMalloc((void**)&h->pin, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) h->pin_cap = (size_t)1 << 20;
+    else { h->pin = nullptr; h->pin_cap = 0; hipGetLastError(); }
     if (hipMalloc((void**)&h->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_MEMORY; }
     hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long));
     {
@@ -200,6 +202,9 @@ static void fh_free_problem(feasthip_ctx* h) {
     h->lu_factors.clear(); h->lu_pivots.clear(); h->lu_valid.clear(); h->lu_z.clear();
     fh_banded_free(h);
     h->kind = 0;
+    h->rs_P = h->rs_basis = h->rs_X = h->rs_R = nullptr;
+    h->rs_m = h->rs_ld = h->rs_rank = h->rs_X_m = h->rs_X_ld = 0;
+    h->rs_T.clear(); h->rs_R_lambda.clear();
 }
 
 extern "C" int feasthip_destroy(feasthip_handle h) {
@@ -221,6 +226,7 @@ extern "C" int feasthip_destroy(feasthip_handle h) {
     for (auto& ep : h->pending_events) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     for (hipEvent_t e : h->event_pool) hipEventDestroy(e);
     if (h->h_progress) hipHostFree((void*)h->h_progress);
+    if (h->pin) hipHostFree(h->pin);
     if (h->lu_ev_next) hipEventDestroy(h->lu_ev_next);
     if (h->lu_ev_rest) hipEventDestroy(h->lu_ev_rest);
     if (h->side_stream) hipStreamDestroy(h->side_stream);
@@ -543,9 +549,55 @@ static int fh_upload_coefs(feasthip_ctx* h, const char* name, const std::vector<
     void* p = nullptr;
     int rc = fh_get_buf(h, name, host.size() * sizeof(cplx), &p);
     if (rc) return rc;
-    FH_CHECK(hipMemcpyAsync(p, host.data(), host.size() * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
-    FH_CHECK(hipStreamSynchronize(h->stream));   // host vector may go out of scope
+    const size_t bytes = host.size() * sizeof(cplx);
+    if (h->pin && bytes <= h->pin_cap / 4) {
+        // staged through a pinned ring: the copy is queued and the caller's vector may go out of scope at once -- no
+        // synchronisation per upload (a FEAST loop makes about twenty of these).  The ring wraps behind a stream
+        // synchronisation, so a slot is never rewritten under a copy that is still queued.
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (h->pin_off + need > h->pin_cap) {
+            FH_CHECK(hipStreamSynchronize(h->stream));
+            h->pin_off = 0;
+        }
+        memcpy(h->pin + h->pin_off, host.data(), bytes);
+        FH_CHECK(hipMemcpyAsync(p, h->pin + h->pin_off, bytes, hipMemcpyHostToDevice, h->stream));
+        h->pin_off += need;
+    } else {
+        FH_CHECK(hipMemcpyAsync(p, host.data(), bytes, hipMemcpyHostToDevice, h->stream));
+        FH_CHECK(hipStreamSynchronize(h->stream));   // host vector may go out of scope
+    }
     *dev = (cplx*)p;
+    return 0;
+}
+
+// Small host -> device copy through the pinned ring (queued, no synchronisation; falls back to a synchronous copy)
+static int fh_upload_small(feasthip_ctx* h, void* dst, const void* src, size_t bytes) {
+    if (h->pin && bytes <= h->pin_cap / 4) {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (h->pin_off + need > h->pin_cap) { FH_CHECK(hipStreamSynchronize(h->stream)); h->pin_off = 0; }
+        memcpy(h->pin + h->pin_off, src, bytes);
+        FH_CHECK(hipMemcpyAsync(dst, h->pin + h->pin_off, bytes, hipMemcpyHostToDevice, h->stream));
+        h->pin_off += need;
+        return 0;
+    }
+    FH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+// Small device -> host copy: lands in the pinned ring (one DMA, no pageable staging), *slot points at it; valid after the
+// caller's next stream synchronisation and until the ring wraps
+static int fh_download_small(feasthip_ctx* h, const void* src, size_t bytes, const void** slot, std::vector<char>& fallback) {
+    if (h->pin && bytes <= h->pin_cap / 4) {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (h->pin_off + need > h->pin_cap) { FH_CHECK(hipStreamSynchronize(h->stream)); h->pin_off = 0; }
+        FH_CHECK(hipMemcpyAsync(h->pin + h->pin_off, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        *slot = h->pin + h->pin_off;
+        h->pin_off += need;
+        return 0;
+    }
+    fallback.resize(bytes);
+    FH_CHECK(hipMemcpyAsync(fallback.data(), src, bytes, hipMemcpyDeviceToHost, h->stream));
+    *slot = fallback.data();
     return 0;
 }
 
@@ -1106,9 +1158,18 @@ struct fh_moment_ctx {
     std::vector<cplx>* sq = nullptr;
 };
 
+// Panels handed in / left behind in the kernels' own row-major layout (resident refinement loop): Qp replaces the import of a
+// column-major dQ, eigres is A q - lambda B q for the Ritz values passed as ritz_lambda (the shared start residual: saves its
+// product), out receives Q_proj as a panel (the export to a column-major dQproj is skipped when that pointer is null).
+struct fh_panel_io {
+    const cplx* Qp = nullptr;
+    const cplx* eigres = nullptr;
+    cplx* out = nullptr;
+};
+
 static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
                                   cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats,
-                                  const fh_moment_ctx* mom = nullptr) {
+                                  const fh_moment_ctx* mom = nullptr, const fh_panel_io* io = nullptr) {
     int rc = fh_check_problem(h, m64);
     if (rc) return rc;
     if (h->zne.empty()) { h->last_error = "no contour set"; return FEASTHIP_ERROR_FPM; }
@@ -1118,14 +1179,23 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
     const int nodes = h->node_count;
     const size_t panel = (size_t)N * ld;
     void* p;
-    if ((rc = fh_get_buf(h, "ca_Qp", panel * sizeof(cplx), &p))) return rc;
-    cplx* Qp = (cplx*)p;
-    if ((rc = fh_get_buf(h, "ca_out", panel * sizeof(cplx), &p))) return rc;
-    cplx* Outp = (cplx*)p;
-    fh_launch_to_panel(dQ, N, N, m, Qp, ld, h->stream, fh_perm(h));
+    cplx* Qp = nullptr;
+    if (io && io->Qp) {
+        Qp = const_cast<cplx*>(io->Qp);          // read only below (the right-hand side when B = I)
+    } else {
+        if ((rc = fh_get_buf(h, "ca_Qp", panel * sizeof(cplx), &p))) return rc;
+        Qp = (cplx*)p;
+        fh_launch_to_panel(dQ, N, N, m, Qp, ld, h->stream, fh_perm(h));
+    }
+    cplx* Outp = io ? io->out : nullptr;
+    if (!Outp) {
+        if ((rc = fh_get_buf(h, "ca_out", panel * sizeof(cplx), &p))) return rc;
+        Outp = (cplx*)p;
+    }
     if (stats) memset(stats, 0, sizeof(*stats));
     if (nodes == 0) {
-        FH_CHECK(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream));
+        if (io && io->out) FH_CHECK(hipMemsetAsync(io->out, 0, panel * sizeof(cplx), h->stream));
+        if (dQproj) FH_CHECK(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream));
         if (dzAq) FH_CHECK(hipMemsetAsync(dzAq, 0, (size_t)m * m * sizeof(cplx), h->stream));
         if (dzSq) FH_CHECK(hipMemsetAsync(dzSq, 0, (size_t)m * m * sizeof(cplx), h->stream));
         FH_CHECK(hipStreamSynchronize(h->stream));
@@ -1209,7 +1279,9 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         const cplx* shared_src = nullptr;
         sum_shared = sum_acc && h->factor_precision == 64 && !getenv("FH_NO_SHARED_START");
         if (sum_shared) {
-            if (ritz_lambda) {
+            if (ritz_lambda && io && io->eigres) {
+                shared_src = io->eigres;                         // left behind by the Ritz step of the previous loop
+            } else if (ritz_lambda) {
                 std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
                 for (int c = 0; c < m; ++c) cb[c] = cmake(-ritz_lambda[c], 0);
                 cplx *dca, *dcb;
@@ -1292,7 +1364,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
         fh_launch_accumulate(Y, panel, dw, nodes, N, ld, sum_acc, Outp, h->real_projection, h->stream);
     }
     fh_prof_end(h);
-    fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream, fh_perm(h));
+    if (dQproj) fh_launch_from_panel(Outp, ld, N, m, dQproj, N, h->stream, fh_perm(h));
 
     // optional moments (variant B): zAq += w_e Q^H Y_e ; zSq += w_e z_e Q^H Y_e
     if (dzAq || dzSq || mom) {
@@ -1407,19 +1479,33 @@ static int fh_contour_apply_local(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
 // on the handle's stream: the image of MPI.Allreduce in src/parallel/feast_mpi.jl:117-119, 856-858 and of the
 // master sum src/parallel/feast_parallel.jl:497-503.  With a communicator node_status is GLOBAL (ne entries,
 // indexed by contour node), without one it is per local node as before.
+// Resident form (rs != null; m <= 64, no moments): the subspace comes in as the panel rs->Q (with, optionally, its
+// eigen-residual panel rs->eigres), the summed Q_proj is left in the panel rs->P (N x rs->ld); column blocks are cut out of
+// / packed into the panels by fh_launch_panel_cols / fh_launch_pack_cols, and the reduce carries N x ld values.
+struct fh_resident_sweep {
+    const cplx* Q; const cplx* eigres; cplx* P; int ld;
+};
+
 static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, const double* ritz_lambda,
-                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats) {
+                                 cplx* dQproj, cplx* dzAq, cplx* dzSq, int* node_status, feasthip_stats* stats,
+                                 const fh_resident_sweep* rs = nullptr) {
     const int nr = fh_comm_nranks(h);
     int64_t c0 = 0, c1 = m64;
     if (h->col_block_hi >= 0) { c0 = std::min(h->col_block_lo, m64); c1 = std::min(std::max(h->col_block_hi, c0), m64); }
     const bool full = (c0 == 0 && c1 == m64);
-    if (nr == 1 && full) return fh_contour_apply_local(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
+    if (nr == 1 && full) {
+        if (rs) {
+            fh_panel_io io; io.Qp = rs->Q; io.eigres = rs->eigres; io.out = rs->P;
+            return fh_contour_apply_panel(h, m64, nullptr, ritz_lambda, nullptr, nullptr, nullptr, node_status, stats, nullptr, &io);
+        }
+        return fh_contour_apply_local(h, m64, dQ, ritz_lambda, dQproj, dzAq, dzSq, node_status, stats);
+    }
     // The shape of the packed reduce depends only on what every rank was called with (N, m, ne, the moment pointers, the
     // projection mode).  An argument error is therefore the same on every rank and may return at once; anything that
     // can fail on ONE rank only (allocations, the sweep, copies) is recorded in local_rc and the rank still joins the
     // reduce with a zeroed payload and its failure flag set -- its peers are waiting in the collective, and RCCL has no
     // timeout.
-    int rc = fh_check_problem(h, m64, 1);
+    int rc = fh_check_problem(h, m64, rs ? 0 : 1);
     if (rc) return rc;
     if (!full && (dzAq || dzSq)) { h->last_error = "contour_apply: moment matrices need the full column block"; return FEASTHIP_ERROR_M0; }
     const int N = (int)fh_N(h), m = (int)m64, nodes = h->node_count, ne = (int)h->zne.size();
@@ -1434,7 +1520,7 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     };
     soft(hipSetDevice(h->device), "hipSetDevice");
     // the reduce buffer comes first: without it this rank cannot join the collective at all
-    const size_t nq = (size_t)N * m * (h->real_projection ? 1 : 2);
+    const size_t nq = (size_t)N * (rs ? rs->ld : m) * (h->real_projection ? 1 : 2);
     const size_t nm = (size_t)m * m * 2;
     const size_t total = nq + (dzAq ? nm : 0) + (dzSq ? nm : 0) + 3 * (size_t)ne + 1;
     double* pack = nullptr;
@@ -1448,8 +1534,43 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
         }
         pack = (double*)p;
     }
-    if (!local_rc && !full) soft(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream), "hipMemsetAsync(Q_proj)");
-    if (!local_rc && c1 > c0) {
+    if (!local_rc && !full && !rs) soft(hipMemsetAsync(dQproj, 0, (size_t)N * m * sizeof(cplx), h->stream), "hipMemsetAsync(Q_proj)");
+    cplx* rs_out = nullptr;                       // resident form: this rank's block of Q_proj, an N x rs_ldw panel
+    int rs_ldw = 0;
+    if (rs && !local_rc && c1 > c0) {
+        const int w = (int)(c1 - c0);
+        rs_ldw = fh_pick_ld(w);
+        fh_panel_io io;
+        void* p = nullptr;
+        int brc = fh_get_buf(h, "rs_Osub", (size_t)N * rs_ldw * sizeof(cplx), &p);
+        rs_out = (cplx*)p;
+        if (!brc && full) { io.Qp = rs->Q; io.eigres = rs->eigres; }
+        if (!brc && !full) {
+            // this rank's columns of the subspace (and of its eigen-residual) as panels of their own
+            if (!(brc = fh_get_buf(h, "rs_Qsub", (size_t)N * rs_ldw * sizeof(cplx), &p))) {
+                fh_launch_panel_cols(rs->Q, rs->ld, (int)c0, w, N, (cplx*)p, rs_ldw, h->stream);
+                io.Qp = (const cplx*)p;
+            }
+            if (!brc && rs->eigres && !(brc = fh_get_buf(h, "rs_Esub", (size_t)N * rs_ldw * sizeof(cplx), &p))) {
+                fh_launch_panel_cols(rs->eigres, rs->ld, (int)c0, w, N, (cplx*)p, rs_ldw, h->stream);
+                io.eigres = (const cplx*)p;
+            }
+        }
+        if (brc) local_rc = brc;
+        else {
+            io.out = rs_out;
+            const std::vector<int> mask = h->col_mask;
+            if (!mask.empty()) {
+                h->col_mask.clear();
+                for (int64_t c = c0; c < c1; ++c) h->col_mask.push_back(c < (int64_t)mask.size() ? mask[c] : 1);
+            }
+            local_rc = fh_contour_apply_panel(h, w, nullptr, ritz_lambda ? ritz_lambda + c0 : nullptr, nullptr, nullptr, nullptr,
+                                              ns.data(), stats, nullptr, &io);
+            h->col_mask = mask;
+        }
+    } else if (rs && !local_rc) {
+        soft(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
+    } else if (!local_rc && c1 > c0) {
         const std::vector<int> mask = h->col_mask;
         if (!mask.empty()) {
             h->col_mask.clear();
@@ -1463,12 +1584,25 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
     }
     if (nr == 1) {
         if (local_rc) return local_rc;
+        if (rs) {                                 // one rank, a column block: the other columns of Q_proj are zero
+            FH_CHECK(hipMemsetAsync(rs->P, 0, (size_t)N * rs->ld * sizeof(cplx), h->stream));
+            if (rs_out) {
+                void* p = nullptr;
+                if ((rc = fh_get_buf(h, "comm_pack", nq * sizeof(double), &p))) return rc;
+                fh_launch_pack_cols(rs_out, rs_ldw, (int)c0, (int)(c1 - c0), N, (double*)p, rs->ld, h->real_projection, h->stream);
+                if (h->real_projection) fh_launch_unpack_real((const double*)p, rs->P, nq, h->stream);
+                else FH_CHECK(hipMemcpyAsync(rs->P, p, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            }
+            FH_CHECK(hipStreamSynchronize(h->stream));
+        }
         if (node_status) for (int e = 0; e < nodes; ++e) node_status[e] = ns[e];
         return 0;
     }
     size_t off = nq;
     if (!local_rc) {
-        if (h->real_projection) fh_launch_pack_real(dQproj, pack, nq, h->stream);
+        if (rs && rs_out) fh_launch_pack_cols(rs_out, rs_ldw, (int)c0, (int)(c1 - c0), N, pack, rs->ld, h->real_projection, h->stream);
+        else if (rs) soft(hipMemsetAsync(pack, 0, nq * sizeof(double), h->stream), "pack Q_proj (no columns)");
+        else if (h->real_projection) fh_launch_pack_real(dQproj, pack, nq, h->stream);
         else soft(hipMemcpyAsync(pack, dQproj, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "pack Q_proj");
         if (dzAq) { soft(hipMemcpyAsync(pack + off, dzAq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "pack zAq"); off += nm; }
         if (dzSq) { soft(hipMemcpyAsync(pack + off, dzSq, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream), "pack zSq"); off += nm; }
@@ -1503,8 +1637,9 @@ static int fh_contour_apply_impl(feasthip_ctx* h, int64_t m64, const cplx* dQ, c
         hipStreamSynchronize(h->stream);          // best effort: leave no work of ours queued behind the error
         return local_rc;
     }
-    if (h->real_projection) fh_launch_unpack_real(pack, dQproj, nq, h->stream);
-    else FH_CHECK(hipMemcpyAsync(dQproj, pack, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    cplx* const qdst = rs ? rs->P : dQproj;
+    if (h->real_projection) fh_launch_unpack_real(pack, qdst, nq, h->stream);
+    else FH_CHECK(hipMemcpyAsync(qdst, pack, nq * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     off = nq;
     if (dzAq) { FH_CHECK(hipMemcpyAsync(dzAq, pack + off, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
     if (dzSq) { FH_CHECK(hipMemcpyAsync(dzSq, pack + off, nm * sizeof(double), hipMemcpyDeviceToDevice, h->stream)); off += nm; }
@@ -2268,6 +2403,341 @@ extern "C" int feasthip_ritz_residual(feasthip_handle h, int64_t r, const void* 
     rc = feasthip_ritz_residual_dev(h, r, dQ, V, lambda, M, normalize, use_B, dX, res);
     if (rc) return rc;
     FH_CHECK(hipMemcpy(X, dX, nb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Resident refinement loop (rows a7, a9-a13 of one FEAST loop without leaving the kernels' panel layout)
+//
+// The per-primitive entry points above speak column-major at the C ABI, so one loop of variant A crossed the boundary seven
+// times (contour_apply in/out, orthonormalize in/out, project in, ritz_residual in/out: k_to_panel / k_from_panel each) and
+// synchronised the stream about twenty times (every small host -> device upload).  Here the panels stay where the kernels
+// left them:
+//   feasthip_contour_apply_resident   Q (imported once, or the Ritz vectors of the previous loop)  ->  Q_proj   [rs_P]
+//   feasthip_rr_reduce_resident       rank + the reduced pencil  (Q_o^H A Q_o, Q_o^H B Q_o)  of the orthonormal basis Q_o of Q_proj
+//   feasthip_rr_ritz_resident         X = Q_o V, normalise, residuals; X becomes the next loop's Q   [rs_X, rs_R]
+//   feasthip_resident_export          column-major copy of X (the converged Ritz vectors, once per solve)
+// The orthonormal basis is never formed when Q_proj is well conditioned (the steady state of FEAST): the Rayleigh-Ritz
+// pairs of a subspace do not depend on the basis, so the reduced pencil is taken on Q_proj with unit columns -- three Gram
+// products (Q^H Q for the test, Q^H A Q, Q^H B Q) queued behind ONE synchronisation, an O(m^2) scaling on the host -- and
+// handed to the host's generalized eigensolver, whose Cholesky factorisation of the B-part does what the Cholesky-QR did;
+// the Ritz vectors are Q_proj (D^-1 V): one tall product instead of two.  The acceptance test is fh_ortho_panel's one-pass
+// condition (equilibrated pivoted-Cholesky ratio > 1e-2, the reference's rank rule with its margin); anything else -- rank
+// deficiency, a ratio that needs the second Cholesky-QR pass -- takes fh_ortho_panel itself on the resident panel, so the
+// rank decisions are the same as the per-primitive path's.
+// The eigen-residual panel A X - B X diag(lambda) the Ritz step forms for its norms is the next sweep's shared start
+// residual (fh_contour_apply_panel: shared_src), which saves that sweep's first operator product.
+// ---------------------------------------------------------------------------------------
+static int fh_rs_panels(feasthip_ctx* h, cplx** P, cplx** X, cplx** R) {
+    const size_t bytes = (size_t)fh_N(h) * FH_MAX_LD * sizeof(cplx);
+    void* p;
+    int rc;
+    if ((rc = fh_get_buf(h, "rs_P", bytes, &p))) return rc;
+    *P = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rs_X", bytes, &p))) return rc;
+    *X = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rs_R", bytes, &p))) return rc;
+    *R = (cplx*)p;
+    return 0;
+}
+
+extern "C" int feasthip_contour_apply_resident(feasthip_handle h, int64_t m64, const void* dQ, const double* ritz_lambda_host,
+                                               int* node_status, feasthip_stats* stats) {
+    int rc = fh_check_problem(h, m64);
+    if (rc) return rc;
+    if (h->zne.empty()) { h->last_error = "no contour set"; return FEASTHIP_ERROR_FPM; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)m64, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    cplx *P, *X, *R;
+    if ((rc = fh_rs_panels(h, &P, &X, &R))) return rc;
+    fh_resident_sweep rs;
+    rs.P = P; rs.ld = ld; rs.eigres = nullptr;
+    if (dQ) {
+        void* p;
+        if ((rc = fh_get_buf(h, "rs_Q0", (size_t)N * FH_MAX_LD * sizeof(cplx), &p))) return rc;
+        fh_launch_to_panel((const cplx*)dQ, N, N, m, (cplx*)p, ld, h->stream, fh_perm(h));
+        rs.Q = (const cplx*)p;
+    } else {
+        if (h->rs_X != X || h->rs_X_m != m || h->rs_X_ld != ld) {
+            h->last_error = "contour_apply_resident: no resident Ritz vectors of this width (pass Q, or run rr_ritz_resident first)";
+            return FEASTHIP_ERROR_M0;
+        }
+        rs.Q = X;
+        if (ritz_lambda_host && h->rs_R == R && (int)h->rs_R_lambda.size() >= m) {
+            bool same = true;
+            for (int c = 0; c < m && same; ++c) same = h->rs_R_lambda[c].y == 0.0 && h->rs_R_lambda[c].x == ritz_lambda_host[c];
+            if (same) rs.eigres = R;
+        }
+    }
+    h->rs_P = nullptr; h->rs_basis = nullptr; h->rs_T.clear(); h->rs_rank = 0;
+    h->mask_live = 1;
+    rc = fh_contour_apply_impl(h, m64, nullptr, ritz_lambda_host, nullptr, nullptr, nullptr, node_status, stats, &rs);
+    h->mask_live = 0;
+    h->col_mask.clear();
+    if (rc) return rc;
+    h->rs_P = P; h->rs_m = m; h->rs_ld = ld;
+    return 0;
+}
+
+extern "C" int feasthip_rr_reduce_resident(feasthip_handle h, int64_t m64, double rank_tol, int hermitize, int* rank,
+                                           void* Aq_host, void* Bq_host) {
+    int rc = fh_check_problem(h, m64);
+    if (rc) return rc;
+    if (!rank || !Aq_host || !Bq_host) { h->last_error = "rr_reduce_resident: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)m64, N = (int)fh_N(h);
+    cplx *Pb, *Xb, *Rb;
+    if ((rc = fh_rs_panels(h, &Pb, &Xb, &Rb))) return rc;
+    if (h->rs_P != Pb || h->rs_m != m) { h->last_error = "rr_reduce_resident: no resident Q_proj of this width"; return FEASTHIP_ERROR_M0; }
+    const int ld = h->rs_ld;
+    cplx* P = h->rs_P;
+    const size_t panel = (size_t)N * ld, g2 = (size_t)ld * ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "pj_W", panel * sizeof(cplx), &p))) return rc;
+    cplx* W = (cplx*)p;
+    if ((rc = fh_get_buf(h, "gram_work", fh_gram_work_elems(ld) * sizeof(cplx), &p))) return rc;
+    cplx* gw = (cplx*)p;
+    if ((rc = fh_get_buf(h, "gram_G3", 3 * g2 * sizeof(cplx), &p))) return rc;
+    cplx* G = (cplx*)p;
+    std::vector<cplx> one(ld, cmake(1, 0)), zero(ld, cmake(0, 0));
+    cplx *d1, *d0;
+    if ((rc = fh_upload_coefs(h, "pj_one", one, &d1))) return rc;
+    if ((rc = fh_upload_coefs(h, "pj_zero", zero, &d0))) return rc;
+    const bool b_id = fh_b_identity(h);
+    // Gram products of `basis`: [0] basis^H basis (want_g0), [1] basis^H A basis, [2] basis^H B basis (B != I); one sync
+    const cplx* Gh = nullptr;
+    std::vector<char> gh_fallback;
+    auto grams = [&](const cplx* basis, bool want_g0) -> int {
+        if (want_g0) { fh_prof_begin(h, "gram"); fh_launch_gram(basis, basis, N, ld, 0, gw, G, h->stream); fh_prof_end(h); }
+        for (int which = 0; which < 2; ++which) {
+            if (which == 1 && b_id) break;
+            fh_op_call oc;
+            oc.m = m;
+            oc.X = basis; oc.x_stride = 0; oc.Y = W; oc.y_stride = 0;
+            oc.coefA = which == 0 ? d1 : d0; oc.coefB = which == 0 ? d0 : d1;
+            oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+            oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+            fh_apply_operator(h, ld, oc);
+            fh_prof_begin(h, "gram");
+            fh_launch_gram(basis, W, N, ld, 0, gw, G + (size_t)(1 + which) * g2, h->stream);
+            fh_prof_end(h);
+        }
+        const void* slot = nullptr;
+        int drc = fh_download_small(h, G, 3 * g2 * sizeof(cplx), &slot, gh_fallback);
+        if (drc) return drc;
+        FH_CHECK(hipStreamSynchronize(h->stream));
+        Gh = (const cplx*)slot;
+        return 0;
+    };
+    // out (r x r, column-major) = Gsrc scaled by 1/(d_i d_j) (d == null: as is), Hermitian part when asked
+    auto emit = [&](const cplx* Gsrc, const double* d, int r, void* out_host) {
+        cplx* out = (cplx*)out_host;
+        for (int j = 0; j < r; ++j)
+            for (int i = 0; i < r; ++i) {
+                cplx g = Gsrc[(size_t)j * ld + i];
+                if (d) g = cscale(g, 1.0 / (d[i] * d[j]));
+                out[(size_t)j * r + i] = g;
+            }
+        if (hermitize)
+            for (int j = 0; j < r; ++j)
+                for (int i = 0; i <= j; ++i) {
+                    const cplx a = out[(size_t)j * r + i], b = cconj(out[(size_t)i * r + j]);
+                    const cplx hm = cmake(0.5 * (a.x + b.x), 0.5 * (a.y + b.y));
+                    out[(size_t)j * r + i] = hm; out[(size_t)i * r + j] = cconj(hm);
+                }
+    };
+    auto identity = [&](int r, void* out_host) {
+        cplx* out = (cplx*)out_host;
+        for (int j = 0; j < r; ++j) for (int i = 0; i < r; ++i) out[(size_t)j * r + i] = cmake(i == j ? 1.0 : 0.0, 0.0);
+    };
+    if ((rc = grams(P, true))) return rc;
+    // ---- implicit basis: the acceptance test of fh_ortho_panel, on the Gram matrix we already have ----
+    bool fast = !getenv("FH_NO_CHOLQR");
+    std::vector<double> dcol(m, 1.0);
+    if (fast) {
+        std::vector<cplx> G0(Gh, Gh + g2);
+        double dmin = 0.0, dmax = 0.0;
+        for (int j = 0; j < m; ++j) {
+            const double g = G0[(size_t)j * ld + j].x;
+            dcol[j] = g > 0.0 && std::isfinite(g) ? std::sqrt(g) : 0.0;
+            dmin = j == 0 ? dcol[j] : std::min(dmin, dcol[j]);
+            dmax = std::max(dmax, dcol[j]);
+        }
+        fast = dmin > 0.0;
+        if (fast) {
+            bool is_real = true;
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i < m; ++i) {
+                    cplx& g = G0[(size_t)j * ld + i];
+                    g = cscale(g, 1.0 / (dcol[i] * dcol[j]));
+                    if (g.y != 0.0) is_real = false;
+                }
+            double ratio;
+            if (is_real) {
+                std::vector<double> Gr((size_t)m * m);
+                for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) Gr[(size_t)j * m + i] = G0[(size_t)j * ld + i].x;
+                ratio = fh_pivoted_cholesky_ratio_real(std::move(Gr), m);
+            } else {
+                ratio = fh_pivoted_cholesky_ratio(std::move(G0), m, ld);
+            }
+            static const bool always_two = getenv("FH_CHOLQR_TWO_PASS") != nullptr;
+            // the one-pass condition of fh_ortho_panel (pivot ratio of the equilibrated Gram matrix > 1e-2: the basis below is
+            // then as good as an orthonormalised one to 1e-14) and the reference's rank rule with the same margin as there
+            fast = ratio > 1e-2 && !always_two && (dmin / dmax) * std::sqrt(ratio) > 1e3 * rank_tol;
+        }
+    }
+    if (fast) {
+        // basis = Q_proj D^-1 (unit columns): its pencil is the equilibrated Gram pair; the orthonormal basis is never formed
+        emit(Gh + g2, dcol.data(), m, Aq_host);
+        emit(b_id ? Gh : Gh + 2 * g2, dcol.data(), m, Bq_host);
+        h->rs_basis = P; h->rs_rank = m;
+        h->rs_T.assign(m, cmake(1, 0));
+        for (int j = 0; j < m; ++j) h->rs_T[j] = cmake(1.0 / dcol[j], 0.0);
+        *rank = m;
+        fh_prof_collect(h);
+        FH_CHECK(hipGetLastError());
+        return 0;
+    }
+    // ---- general path: the rank-revealing orthonormalisation on the resident panel, then the projections of its result ----
+    if ((rc = fh_get_buf(h, "or_out", (size_t)N * FH_MAX_LD * sizeof(cplx), &p))) return rc;
+    cplx* Out = (cplx*)p;
+    cplx* res = nullptr;
+    int r = 0;
+    if ((rc = fh_ortho_panel(h, m, ld, P, Out, rank_tol, 0.0, m, &r, &res))) return rc;
+    h->rs_P = nullptr;                            // (the orthonormalisation may have overwritten the projection panel)
+    *rank = r;
+    h->rs_rank = r; h->rs_T.clear(); h->rs_basis = res;
+    if (r == 0) { fh_prof_collect(h); return 0; }
+    if ((rc = grams(res, false))) return rc;
+    emit(Gh + g2, nullptr, r, Aq_host);
+    if (b_id) identity(r, Bq_host);               // orthonormal basis, B = I: exactly I (src/dense/feast_dense.jl:255-259)
+    else emit(Gh + 2 * g2, nullptr, r, Bq_host);
+    fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int feasthip_rr_ritz_resident(feasthip_handle h, int64_t r64, const void* V_host, const double* lambda_host, int64_t M,
+                                         int normalize, int use_B, double* res_host) {
+    int rc = fh_check_problem(h, r64);
+    if (rc) return rc;
+    if (!V_host || !lambda_host) { h->last_error = "rr_ritz_resident: null argument"; return FEASTHIP_ERROR_INTERNAL; }
+    if (M < 0 || M > r64) { h->last_error = "rr_ritz_resident: M out of range"; return FEASTHIP_ERROR_M0; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int r = (int)r64, N = (int)fh_N(h);
+    cplx *Pb, *Xp, *Rp;
+    if ((rc = fh_rs_panels(h, &Pb, &Xp, &Rp))) return rc;
+    if (!h->rs_basis || h->rs_rank != r) { h->last_error = "rr_ritz_resident: run rr_reduce_resident first (rank mismatch)"; return FEASTHIP_ERROR_M0; }
+    const int ld = h->rs_ld;
+    void* p;
+    if ((rc = fh_get_buf(h, "rz_V", (size_t)ld * ld * sizeof(cplx), &p))) return rc;
+    cplx* dV = (cplx*)p;
+    const int nblk_op = fh_op_nblk(h, ld), nblk_vec = fh_vec_nblk(N, ld);
+    if ((rc = fh_get_buf(h, "rz_part", (size_t)std::max(nblk_op, nblk_vec) * ld * sizeof(cplx), &p))) return rc;
+    cplx* part = (cplx*)p;
+    if ((rc = fh_get_buf(h, "rz_dots", (size_t)ld * sizeof(cplx), &p))) return rc;
+    cplx* ddots = (cplx*)p;
+    // V padded to ld x ld; the implicit basis is Q_proj D^-1, so X = Q_proj (D^-1 V)
+    std::vector<cplx> Vp((size_t)ld * ld, cmake(0, 0));
+    const cplx* Vh = (const cplx*)V_host;
+    const bool scaled = !h->rs_T.empty();
+    for (int j = 0; j < r; ++j)
+        for (int i = 0; i < r; ++i) {
+            const cplx v = Vh[(size_t)j * r + i];
+            Vp[(size_t)j * ld + i] = scaled ? cscale(v, h->rs_T[i].x) : v;
+        }
+    if ((rc = fh_upload_small(h, dV, Vp.data(), Vp.size() * sizeof(cplx)))) return rc;
+    h->rs_X = nullptr; h->rs_R = nullptr;
+    fh_prof_begin(h, "ritz");
+    fh_launch_small_matmul(h->rs_basis, dV, N, ld, Xp, h->stream);
+    fh_prof_end(h);
+    if (normalize && M > 0) {
+        fh_launch_dot_cols(Xp, Xp, N, ld, part, ddots, h->stream);
+        fh_launch_normalize_cols(Xp, ddots, N, ld, (int)M, h->stream);
+    }
+    // R = A X - B X diag(lambda) for all r columns (the next sweep's start residual); res_j = ||R_j|| / max(|lambda_j|, 1), j < M
+    std::vector<cplx> ca(ld, cmake(1, 0)), cb(ld, cmake(0, 0));
+    const bool lam_in_op = use_B || fh_b_identity(h);
+    for (int c = 0; c < r; ++c) cb[c] = lam_in_op ? cmake(-lambda_host[2 * c], -lambda_host[2 * c + 1]) : cmake(0, 0);
+    cplx *dca, *dcb;
+    if ((rc = fh_upload_coefs(h, "rz_coefA", ca, &dca))) return rc;
+    if ((rc = fh_upload_coefs(h, "rz_coefB", cb, &dcb))) return rc;
+    fh_op_call oc;
+    oc.m = r;
+    oc.X = Xp; oc.x_stride = 0; oc.Y = Rp; oc.y_stride = 0; oc.coefA = dca; oc.coefB = dcb;
+    oc.Bvec = nullptr; oc.b_stride = 0; oc.U = nullptr; oc.u_stride = 0; oc.dot_mode = 0;
+    oc.partial1 = nullptr; oc.partial2 = nullptr; oc.node_active = nullptr; oc.nodes = 1;
+    fh_apply_operator(h, ld, oc);
+    if (!lam_in_op) {
+        // RCI-style residual without B: R = A X - X diag(lambda)  (src/kernel/feast_kernel.jl:899-906)
+        std::vector<cplx> lam(ld, cmake(0, 0));
+        for (int c = 0; c < r; ++c) lam[c] = cmake(lambda_host[2 * c], lambda_host[2 * c + 1]);
+        cplx* dl;
+        if ((rc = fh_upload_coefs(h, "rz_lam", lam, &dl))) return rc;
+        fh_launch_axpy_cols(Rp, Xp, dl, N, ld, h->stream);
+    }
+    const cplx* dots_h = nullptr;
+    std::vector<char> dots_fb;
+    if (M > 0 && res_host) {
+        fh_launch_dot_cols(Rp, Rp, N, ld, part, ddots, h->stream);
+        const void* slot = nullptr;
+        if ((rc = fh_download_small(h, ddots, ld * sizeof(cplx), &slot, dots_fb))) return rc;
+        dots_h = (const cplx*)slot;
+    }
+    // the rank dropped below the panel's padded width (64 -> 32 / 16 columns): the next sweep works on the narrower panel
+    int ldx = ld;
+    if (fh_pick_ld(r) < ld) {
+        ldx = fh_pick_ld(r);
+        if ((rc = fh_get_buf(h, "rs_tmp", (size_t)N * FH_MAX_LD * sizeof(cplx), &p))) return rc;
+        cplx* tmp = (cplx*)p;
+        for (cplx* pan : {Xp, Rp}) {
+            fh_launch_panel_cols(pan, ld, 0, r, N, tmp, ldx, h->stream);
+            FH_CHECK(hipMemcpyAsync(pan, tmp, (size_t)N * ldx * sizeof(cplx), hipMemcpyDeviceToDevice, h->stream));
+        }
+    }
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (M > 0 && res_host)
+        for (int c = 0; c < (int)M; ++c) {
+            const double la = std::hypot(lambda_host[2 * c], lambda_host[2 * c + 1]);
+            res_host[c] = std::sqrt(dots_h[c].x) / std::max(la, 1.0);
+        }
+    h->rs_X = Xp; h->rs_X_m = r; h->rs_X_ld = ldx;
+    h->rs_R_lambda.assign(ld, cmake(0, 0));
+    if (use_B || fh_b_identity(h)) {                  // the start residual of the sweeps is the one WITH B
+        for (int c = 0; c < r; ++c) h->rs_R_lambda[c] = cmake(lambda_host[2 * c], lambda_host[2 * c + 1]);
+        h->rs_R = Rp;
+    }
+    fh_prof_collect(h);
+    FH_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int feasthip_resident_export(feasthip_handle h, int which, int64_t ncols, void* dX) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
+    if (!dX) { h->last_error = "resident_export: null destination"; return FEASTHIP_ERROR_INTERNAL; }
+    const cplx* src = which == 0 ? h->rs_X : h->rs_P;
+    const int have = which == 0 ? h->rs_X_m : h->rs_m, ld = which == 0 ? h->rs_X_ld : h->rs_ld;
+    if (!src || ncols < 0 || ncols > have) { h->last_error = "resident_export: no such resident panel / too many columns"; return FEASTHIP_ERROR_M0; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int N = (int)fh_N(h);
+    if (ncols > 0) fh_launch_from_panel(src, ld, N, (int)ncols, (cplx*)dX, N, h->stream, fh_perm(h));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int feasthip_resident_import(feasthip_handle h, int which, int64_t ncols, const void* dX) {
+    int rc = fh_check_problem(h, ncols);
+    if (rc) return rc;
+    if (!dX) { h->last_error = "resident_import: null source"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    const int m = (int)ncols, ld = fh_pick_ld(m), N = (int)fh_N(h);
+    cplx *P, *X, *R;
+    if ((rc = fh_rs_panels(h, &P, &X, &R))) return rc;
+    fh_launch_to_panel((const cplx*)dX, N, N, m, which == 0 ? X : P, ld, h->stream, fh_perm(h));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    if (which == 0) { h->rs_X = X; h->rs_X_m = m; h->rs_X_ld = ld; h->rs_R = nullptr; h->rs_R_lambda.clear(); }
+    else { h->rs_P = P; h->rs_m = m; h->rs_ld = ld; h->rs_basis = nullptr; h->rs_T.clear(); h->rs_rank = 0; }
     return 0;
 }
 

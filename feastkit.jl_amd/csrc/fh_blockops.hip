@@ -65,6 +65,39 @@ void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int6
 }
 
 // ---------------------------------------------------------------------------------------
+// resident refinement loop (feasthip_*_resident): column blocks of panels, packing for the per-loop reduce
+// ---------------------------------------------------------------------------------------
+// dst (N x ldd panel, zero padded) = columns [c0, c0 + w) of src (N x lds panel)
+__global__ __launch_bounds__(FH_BLOCK) void k_panel_cols(const cplx* __restrict__ src, int lds, int c0, int w, size_t total,
+                                                          cplx* __restrict__ dst, int ldd) {
+    const int c = threadIdx.x % ldd;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const size_t row = e / ldd;
+        dst[e] = (c < w) ? src[row * lds + c0 + c] : cmake(0, 0);
+    }
+}
+void fh_launch_panel_cols(const cplx* src, int lds, int c0, int w, int N, cplx* dst, int ldd, hipStream_t st) {
+    hipLaunchKernelGGL(k_panel_cols, dim3(fh_vec_nblk(N, ldd)), dim3(FH_BLOCK), 0, st, src, lds, c0, w, (size_t)N * ldd, dst, ldd);
+}
+// pack[row * ldd * (real ? 1 : 2) + ...] : the w columns of src (N x lds panel) go to columns [c0, c0 + w) of an N x ldd
+// array of reals (real_only) or interleaved complex values; every other entry of the array is written as zero, so that the
+// sum over ranks with disjoint column blocks assembles the full panel
+__global__ __launch_bounds__(FH_BLOCK) void k_pack_cols(const cplx* __restrict__ src, int lds, int c0, int w, size_t total,
+                                                         double* __restrict__ dst, int ldd, int real_only) {
+    const int c = threadIdx.x % ldd;
+    const bool mine = c >= c0 && c < c0 + w;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const size_t row = e / ldd;
+        const cplx v = mine ? src[row * lds + (c - c0)] : cmake(0, 0);
+        if (real_only) dst[e] = v.x;
+        else { dst[2 * e] = v.x; dst[2 * e + 1] = v.y; }
+    }
+}
+void fh_launch_pack_cols(const cplx* src, int lds, int c0, int w, int N, double* dst, int ldd, int real_only, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_cols, dim3(fh_vec_nblk(N, ldd)), dim3(FH_BLOCK), 0, st, src, lds, c0, w, (size_t)N * ldd, dst, ldd, real_only);
+}
+
+// ---------------------------------------------------------------------------------------
 // dst = [extra +] sum_e w[e] X[e]   (fixed summation order => bitwise reproducible)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(FH_BLOCK) void k_accumulate(const cplx* __restrict__ X, size_t node_stride,

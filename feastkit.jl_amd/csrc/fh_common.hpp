@@ -162,6 +162,21 @@ struct feasthip_ctx {
     // workspace (grown lazily)
     std::map<std::string, std::pair<void*, size_t>> bufs;
 
+    // pinned staging ring of the small host -> device uploads (per-column coefficients, weights): fh_upload_coefs
+    char* pin = nullptr; size_t pin_cap = 0, pin_off = 0;
+
+    // resident refinement loop (feasthip_contour_apply_resident / rr_reduce_resident / rr_ritz_resident): the panels of one
+    // FEAST loop stay on the device in the kernels' own row-major layout between the calls; pointers into `bufs`, dropped
+    // (rs_epoch bumped) whenever the problem changes
+    int rs_m = 0, rs_ld = 0;                    // columns / padded row length of the projection panel
+    cplx* rs_P = nullptr;                       // Q_proj of the last resident sweep, summed over the ranks
+    cplx* rs_basis = nullptr;                   // what the Ritz step multiplies: rs_P, or the orthonormalised panel of the fallback
+    std::vector<cplx> rs_T;                     // implicit basis Q_proj D^-1: the m diagonal entries 1 / ||column||; empty = the basis is used as is
+    int rs_rank = 0;
+    cplx* rs_X = nullptr; int rs_X_m = 0, rs_X_ld = 0;   // Ritz vectors of the last resident Ritz step: the next sweep's subspace
+    cplx* rs_R = nullptr;                       // A X - B X diag(lambda) of that step: the next sweep's shared start residual
+    std::vector<cplx> rs_R_lambda;              // the lambda it was formed with
+
     // dense LU cache: per local node factors + pivots
     std::vector<void*> lu_factors;
     std::vector<int*> lu_pivots;

@@ -131,6 +131,10 @@ void fh_launch_gm_finish_cycle(const fh_gmres_args& a, int ld, cplx* X, size_t x
 // perm != null: panel row i holds the caller's row perm[i] (block order of a renumbered sparse matrix)
 void fh_launch_to_panel(const cplx* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st, const int* perm = nullptr);
 void fh_launch_from_panel(const cplx* src, int ld, int N, int m, cplx* dst, int64_t ldd, hipStream_t st, const int* perm = nullptr);
+// resident refinement loop: dst (N x ldd panel, zero padded) = columns [c0, c0 + w) of the N x lds panel src; and the same
+// columns written into columns [c0, c0 + w) of an N x ldd array of reals / interleaved complex values (zeros elsewhere)
+void fh_launch_panel_cols(const cplx* src, int lds, int c0, int w, int N, cplx* dst, int ldd, hipStream_t st);
+void fh_launch_pack_cols(const cplx* src, int lds, int c0, int w, int N, double* dst, int ldd, int real_only, hipStream_t st);
 // real column-major source -> complex panel
 void fh_launch_to_panel_real(const double* src, int64_t lds, int N, int m, cplx* dst, int ld, hipStream_t st);
 // dst = sum_e w[e] * X[e]

@@ -314,6 +314,55 @@ class HipEngine:
             return dP, status, self.last_stats, dA.cpu().numpy().T.copy(), dS.cpu().numpy().T.copy()
         return dP, status, self.last_stats
 
+    # -- the refinement loop with resident panels (feasthip_*_resident: nothing crosses the ABI between the calls of a loop) --
+    resident = True
+
+    def contour_apply_resident(self, dQ, m, ritz_lambda=None):
+        """The sweep of contour_apply with Q_proj left resident in the library.  dQ: device block to import, or None to
+        sweep the Ritz vectors the last rr_ritz_resident left behind.  Returns (status, stats)."""
+        self._sync_stream()
+        status = np.zeros(max(1, self.ne), dtype=np.int32)
+        stats = FeastHipStats()
+        lam = None if ritz_lambda is None else np.ascontiguousarray(ritz_lambda, dtype=np.float64)
+        self._chk(self.lib.feasthip_contour_apply_resident(self.h, int(m), C.c_void_p(dQ.data_ptr()) if dQ is not None else None,
+                                                           _np_ptr(lam), _np_ptr(status), C.byref(stats)))
+        self.last_stats = stats.asdict()
+        return status, self.last_stats
+
+    def rr_reduce_resident(self, m, rank_tol, hermitize=True):
+        """rank of the resident Q_proj and the reduced pencil (Q_o^H A Q_o, Q_o^H B Q_o) of its orthonormal basis."""
+        rank = C.c_int(0)
+        Aq = np.zeros((m, m), dtype=np.complex128, order="F")
+        Bq = np.zeros((m, m), dtype=np.complex128, order="F")
+        self._chk(self.lib.feasthip_rr_reduce_resident(self.h, int(m), float(rank_tol), int(bool(hermitize)), C.byref(rank),
+                                                       _np_ptr(Aq), _np_ptr(Bq)))
+        r = int(rank.value)
+        if r == m:
+            return r, Aq, Bq
+        # the library wrote r x r matrices contiguously
+        return r, np.asfortranarray(Aq.ravel(order="F")[:r * r].reshape((r, r), order="F")), \
+            np.asfortranarray(Bq.ravel(order="F")[:r * r].reshape((r, r), order="F"))
+
+    def rr_ritz_resident(self, r, V, lam, M, normalize=True, use_B=True):
+        """Ritz vectors X = Q_o V (left resident: the next sweep's subspace) and the residuals of the first M."""
+        Vf = np.asfortranarray(V, dtype=np.complex128)
+        lamc = np.ascontiguousarray(lam, dtype=np.complex128)
+        res = np.zeros(max(1, r), dtype=np.float64)
+        self._chk(self.lib.feasthip_rr_ritz_resident(self.h, int(r), _np_ptr(Vf), _np_ptr(lamc), int(M), int(normalize), int(use_B),
+                                                     _np_ptr(res)))
+        return res[:M].copy()
+
+    def import_resident(self, dX, ncols, which=0):
+        """A column-major device block becomes the resident subspace (which = 0) or the resident Q_proj (which = 1)."""
+        self._sync_stream()
+        self._chk(self.lib.feasthip_resident_import(self.h, int(which), int(ncols), C.c_void_p(dX.data_ptr())))
+
+    def export_resident(self, ncols, which=0):
+        """Column-major device block (ncols x N tensor) of the resident Ritz vectors (which = 0) or Q_proj (which = 1)."""
+        out = self.torch.empty((max(int(ncols), 1), self.N), dtype=self.torch.complex128, device=self.device)
+        self._chk(self.lib.feasthip_resident_export(self.h, int(which), int(ncols), C.c_void_p(out.data_ptr())))
+        return out[:int(ncols)]
+
     def orthonormalize(self, dQ, m, rank_tol):
         self._sync_stream()
         rank = C.c_int(0)

@@ -156,7 +156,7 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                         solver_maxiter=500, solver_restart=30, warm_start=True, inner_rtol=None,
                         real_projection=None, group=None, Q0=None, seed=20260515, contour=None, trace=None,
                         preloaded=False, node_assignment="block", inner_precision=64, column_groups=1,
-                        spurious_filter=True, contour_policy=None, eps_floor=0.0, abort_check=None):
+                        spurious_filter=True, contour_policy=None, eps_floor=0.0, abort_check=None, resident_panels=True):
     """Variant A on the :hip engine.  Returns FeastResult (complex Ritz vectors, like
     _feast_dense_complex_hermitian; real-symmetric callers take real.(q) as the reference
     does, src/dense/feast_dense.jl:372-387).
@@ -324,6 +324,11 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
 
     epsout_mp = math.inf                     # outer residual of the previous loop (refinement tolerance of complex64 factors)
     t_loops = time.perf_counter()
+    # The refinement loop with resident panels (engine.contour_apply_resident / rr_reduce_resident / rr_ritz_resident): one
+    # 64-column panel, reduced eigenproblem on the host.  The per-primitive calls remain for wide subspaces (M0 > 64), the
+    # device eigensolver and engines without the resident entry points.
+    resident = bool(getattr(engine, "resident", False)) and M0 <= 64 and reduced_solver != "device" and resident_panels
+    have_ritz = False
     # one BLAS thread for the whole solve; the `with` releases the process-wide limit on every way out, including an
     # exception from the engine inside the loop (FeastHipError, a poisoned handle)
     with small_lapack():
@@ -349,7 +354,13 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                                   factor_precision=32, cache_factors=True)
             # one call = this rank's (nodes x column block) sweep + the packed all-reduce inside the C ABI:
             # dP and status come back summed over all ranks (status indexed by contour node when world > 1)
-            dP, status, st = engine.contour_apply(dQ, active, lam_guess)
+            if resident:
+                # resident panels: Q_proj stays in the library in the kernels' layout; after the first loop the subspace is
+                # the Ritz block the previous loop left there (dQ is None)
+                dP = None
+                status, st = engine.contour_apply_resident(dQ, active, lam_guess)
+            else:
+                dP, status, st = engine.contour_apply(dQ, active, lam_guess)
             if my_cgs > 1:
                 engine.set_column_block(0, -1)
             ph["apply"] += tick() - t_
@@ -390,8 +401,13 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                 break
 
             t_ = tick()
-            rank_q = engine.orthonormalize(dP, active, SQRT_EPS)       # _feast_qr_compress!
-            ph["ortho"] += tick() - t_
+            if resident:
+                # _feast_qr_compress! and the projections in one call: rank + (Q_o^H A Q_o, Q_o^H B Q_o)
+                rank_q, Sq, Aq = engine.rr_reduce_resident(active, SQRT_EPS)
+                ph["project"] += tick() - t_
+            else:
+                rank_q = engine.orthonormalize(dP, active, SQRT_EPS)       # _feast_qr_compress!
+                ph["ortho"] += tick() - t_
             if rank_q == 0:
                 info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
                 break
@@ -425,9 +441,10 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                     dQ = dX
                     ritz_lambda = lam_sorted.copy()
                     continue
-            t_ = tick()
-            Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
-            ph["project"] += tick() - t_
+            if not resident:
+                t_ = tick()
+                Sq, Aq = engine.project(dP, rank_q, bilinear=False, hermitize=True)
+                ph["project"] += tick() - t_
             t_ = tick()
             try:
                 lam_red, v_red = _reduced_hermitian_eig(Sq, Aq)
@@ -447,7 +464,10 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                 info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
                 break
             t_ = tick()
-            dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+            if resident:
+                dX, res = None, engine.rr_ritz_resident(rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+            else:
+                dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
             n_spurious = 0
             if inexact and spurious_filter and loop_idx >= 1 and M > 1:
                 # Inexact inner solves leave solver noise in the guard columns.  Its Ritz values are arbitrary; one that
@@ -465,10 +485,14 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                     lam_sorted = lam_sorted[order]
                     V_sorted = np.asfortranarray(V_sorted[:, order])
                     M = M - n_spurious
-                    dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+                    if resident:
+                        res = engine.rr_ritz_resident(rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
+                    else:
+                        dX, res = engine.ritz_residual(dP, rank_q, V_sorted, lam_sorted, M, normalize=True, use_B=True)
                 else:
                     n_spurious = 0
             ph["ritz"] += tick() - t_
+            have_ritz = True
             lam_vec[:rank_q] = lam_sorted
             if M > 0:
                 res_vec[:M] = res
@@ -547,7 +571,10 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
     if M_found == 0 and info == 0:
         info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
     # only the M converged Ritz vectors cross PCIe (the block is column-major: the first M rows of the tensor)
-    q = engine.download(dX[:M_found], M_found) if (dX is not None and M_found > 0) else np.zeros((N, 0), dtype=np.complex128)
+    if resident and have_ritz and M_found > 0:
+        q = engine.download(engine.export_resident(M_found), M_found)
+    else:
+        q = engine.download(dX[:M_found], M_found) if (dX is not None and M_found > 0) else np.zeros((N, 0), dtype=np.complex128)
     return FeastResult(lam_vec[:M_found].copy(), q, M_found, res_vec[:M_found].copy(), info, epsout, loop_count, stats)
 
 

@@ -232,6 +232,44 @@ int  feasthip_contour_apply_dev(feasthip_handle h, int64_t m, const void* dQ,
                                 const double* ritz_lambda_host, void* dQproj,
                                 void* dzAq, void* dzSq, int* node_status, feasthip_stats* stats);
 
+/* ---- the refinement loop with resident panels ---------------------------------------------------------------------
+ * One loop of variant A -- contour sweep, _feast_qr_compress!, the reduced pencil, Ritz vectors, residuals
+ * (src/dense/feast_dense.jl:171-337, src/sparse/feast_sparse.jl:318-478) -- as three calls whose N x m blocks never
+ * leave the device NOR the kernels' own layout between them (m <= 64, no moment matrices).  The per-primitive entry
+ * points below compute the same quantities through column-major blocks at every call; a shim that does not need the
+ * intermediate blocks on the host should prefer these.
+ *
+ * feasthip_contour_apply_resident: the sweep of feasthip_contour_apply_dev.  dQ != NULL: the N x m subspace (column
+ *   major, device) is imported; dQ == NULL: the Ritz vectors left by the last feasthip_rr_ritz_resident are the subspace
+ *   (m must be that call's r) and, when ritz_lambda equals that call's lambda, its residual panel A X - B X diag(lambda)
+ *   starts the warm-started Krylov sweeps (one operator product saved).  Q_proj stays resident, summed over the ranks of
+ *   an attached communicator (node_status as in feasthip_contour_apply_dev).
+ * feasthip_rr_reduce_resident: *rank = numerical rank of the resident Q_proj under the reference's rule
+ *   (src/core/feast_aux.jl:101-131); Aq and Bq receive the rank x rank pencil (Q_b^H A Q_b, Q_b^H B Q_b) (column-major, host;
+ *   Hermitian parts when hermitize != 0, src/core/feast_aux.jl:84-92) of a basis Q_b of its range, to be handed to the
+ *   generalized reduced eigensolver as the reference does (eigen(Hermitian(Sq), Hermitian(Aq)), src/dense/feast_dense.jl:272).
+ *   Q_b is Q_proj with its columns scaled to unit length when that basis is well conditioned (the steady state of FEAST:
+ *   the test is the one-pass condition of the Cholesky-QR, pivot ratio of the equilibrated Gram matrix > 1e-2) -- no
+ *   orthonormal basis is formed, Bq is then the equilibrated Gram-type matrix, not I; otherwise Q_b is the orthonormal
+ *   basis of the rank-revealing orthonormalisation (Bq = exactly I for B = I, src/dense/feast_dense.jl:255-259).
+ * feasthip_rr_ritz_resident: X = Q_b V for the r = rank columns of V (r x r, host, column-major), the first M columns
+ *   normalised when normalize != 0, res[j] = ||A x_j - lambda_j B x_j|| / max(|lambda_j|, 1) for j < M (use_B = 0: without
+ *   B, the RCI kernels' residual); lambda: r complex values (2 r doubles).  X stays resident as the next sweep's subspace.
+ *   May be called again with another V / M for the same reduction (spurious-pair reordering).
+ * feasthip_resident_export: column-major copy (N x ncols, device) of the first ncols resident Ritz vectors (which = 0) or
+ *   of the resident Q_proj (which = 1): the converged eigenvectors leave the device once per solve.
+ * Replaces the bodies of src/dense/feast_dense.jl:234-337 and src/sparse/feast_sparse.jl:372-478 between two sweeps.      */
+int  feasthip_contour_apply_resident(feasthip_handle h, int64_t m, const void* dQ, const double* ritz_lambda_host,
+                                     int* node_status, feasthip_stats* stats);
+int  feasthip_rr_reduce_resident(feasthip_handle h, int64_t m, double rank_tol, int hermitize, int* rank,
+                                 void* Aq_host, void* Bq_host);
+int  feasthip_rr_ritz_resident(feasthip_handle h, int64_t r, const void* V_host, const double* lambda_host, int64_t M,
+                               int normalize, int use_B, double* res_host);
+int  feasthip_resident_export(feasthip_handle h, int which, int64_t ncols, void* dX);
+/* The counterpart: a column-major N x ncols device block becomes the resident subspace (which = 0: resume from a saved
+ * subspace, the reference's fpm[5] = 1 start) or the resident Q_proj (which = 1: a projection computed elsewhere). */
+int  feasthip_resident_import(feasthip_handle h, int which, int64_t ncols, const void* dX);
+
 /* Rank-revealing orthonormalisation of Q[:, 0:m] in place.  Column-pivoted
  * Gram-Schmidt with re-orthogonalisation; rank = #{ |R_ii| > max(rank_tol, eps*max(N,m))*|R_11| },
  * the rule of _feast_qr_compress! (src/core/feast_aux.jl:101-131).  On return the first

@@ -27,6 +27,6 @@ dt = time.perf_counter() - t0
 eng.profile_enable(False)
 its = reps * maxit * nodes
 print(f"nodes={nodes} M={M} maxit={maxit}: {dt*1e3/ (reps*maxit):.3f} ms per iteration (all nodes), {dt*1e3/its:.4f} ms per node-iteration")
-for cls in ("spmm", "bicg_xr", "bicg_p", "bicg_s", "cocg_xr", "cocg_p", "dot_finalize"):
+for cls in ("spmm", "bicg_xr", "bicg_p", "bicg_s", "cocg_xr", "cocg_p", "cocg_vec", "dot_finalize"):
     ms, n = eng.profile_get(cls)
     print(f"  {cls:14s} launches {n:5d} avg {ms/max(n,1)*1e3:8.1f} us")

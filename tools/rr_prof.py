@@ -52,3 +52,17 @@ for cls in ("gram","ortho","small_matmul","spmm","project","ritz","resid","norma
         ms, n = eng.profile_get(cls)
         if n: print(f"  class {cls:12s} launches/10 {n/10:5.1f}  ms per RR {ms/10:7.3f}")
     except Exception as e: pass
+# ---- the same step through the resident entry points (round 4) ----
+print("--- resident ---")
+eng.import_resident(dP0, M0, which=1)
+def reduce_res():
+    eng.import_resident(dP0, M0, which=1)
+    return eng.rr_reduce_resident(M0, 1.5e-8)
+print("import (to_panel+sync) %.1f us" % T(lambda: eng.import_resident(dP0, M0, which=1)))
+print("rr_reduce (+import)   %.1f us" % T(reduce_res))
+r2, Sq2, Aq2 = reduce_res()
+l2, v2 = hb._reduced_hermitian_eig(Sq2, Aq2)
+p2, M2 = hb._reorder_by_interval(l2, bench.EMIN, bench.EMAX, r2)
+V2 = np.asfortranarray(v2[:, p2]); ls2 = l2[p2]
+print("rank", r2, "max |lambda - legacy|", float(np.abs(np.sort(l2) - np.sort(lam_red)).max()))
+print("rr_ritz               %.1f us" % T(lambda: eng.rr_ritz_resident(r2, V2, ls2, max(M2, 44))))
