@@ -24,6 +24,14 @@ class FeastHipStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class FeastHipPolicy(C.Structure):
+    """feasthip_policy (include/feasthip.h): state of the inexact-mode host policy for one solve."""
+    _fields_ = [("Emin", C.c_double), ("Emax", C.c_double), ("inner_rtol", C.c_double), ("outer_tol", C.c_double),
+                ("ne", C.c_int), ("quadrature", C.c_int), ("steer", C.c_int), ("aspect", C.c_int), ("cap", C.c_int),
+                ("inner_cap", C.c_int), ("base_cap", C.c_int), ("n_hist", C.c_int), ("eps_prev", C.c_double),
+                ("eps_hist", C.c_double * 3), ("next_rtol", C.c_double), ("last_reach", C.c_double)]
+
+
 # every symbol include/feasthip.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _pi, _pd, _pi64 = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int64)
@@ -77,6 +85,11 @@ SYMBOLS = {
     "feasthip_profile_get": (_i, [_vp, C.c_char_p, _pd, _pi64]),
     "feasthip_profile_set_period": (_i, [_vp, _i]),
     "feasthip_profile_get_work": (_i, [_vp, C.c_char_p, _pd]),
+    "feasthip_policy_init": (_i, [_vp, _d, _d, _i, _i, _d, _d, _i, _i, _i]),
+    "feasthip_policy_update": (_i, [_vp, _d, _i, _i, _vp, _i]),
+    "feasthip_policy_set_aside": (_i, [_vp, _i, _vp]),
+    "feasthip_policy_filter_ratio": (_d, [_d, _d, _i, _i, _i, _d, _vp, _i]),
+    "feasthip_policy_reach": (_d, [_vp, _i, _d, _d, _d]),
 }
 
 UNIQUE_ID_BYTES = 128      # FEASTHIP_UNIQUE_ID_BYTES

@@ -262,6 +262,7 @@ static inline cplx fh_ing_zero(cplx) { return cmake(0, 0); }
 static inline cplx fh_ing_add(cplx a, cplx b) { return cadd(a, b); }
 #define FH_INGEST_STORAGE_CSR FEASTHIP_STORAGE_CSR
 #include "fh_ingest.hpp"       // host side of the ingest (pure C++; also compiled under ASan/UBSan by tests/host_ingest_harness.cpp)
+#include "fh_policy.hpp"       // host policy of the inexact mode (pure C++), exported as feasthip_policy_*
 
 template <typename VT>
 static int set_csr_typed(feasthip_ctx* h, int64_t N, int index_base, int storage, int64_t nnzA, const int64_t* ptrA,
@@ -2739,6 +2740,86 @@ extern "C" int feasthip_resident_import(feasthip_handle h, int which, int64_t nc
     if (which == 0) { h->rs_X = X; h->rs_X_m = m; h->rs_X_ld = ld; h->rs_R = nullptr; h->rs_R_lambda.clear(); }
     else { h->rs_P = P; h->rs_m = m; h->rs_ld = ld; h->rs_basis = nullptr; h->rs_T.clear(); h->rs_rank = 0; }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Host policy of the inexact FEAST mode (fh_policy.hpp): exported so that host shims call it instead of re-porting it
+// ---------------------------------------------------------------------------------------
+extern "C" int feasthip_policy_init(feasthip_policy* p, double Emin, double Emax, int ne, int quadrature, double inner_rtol,
+                                    double outer_tol, int solver_maxiter, int steer, int fpm18) {
+    if (!p || !(Emax > Emin) || ne < 1 || !(inner_rtol > 0.0) || solver_maxiter < 1) return FEASTHIP_ERROR_FPM;
+    memset(p, 0, sizeof(*p));
+    p->Emin = Emin; p->Emax = Emax; p->inner_rtol = inner_rtol; p->outer_tol = outer_tol;
+    p->ne = ne; p->quadrature = quadrature;
+    p->steer = (steer && (quadrature == 0 || quadrature == 1)) ? 1 : 0;
+    p->cap = 8000; p->inner_cap = p->base_cap = solver_maxiter;
+    p->eps_prev = INFINITY; p->next_rtol = inner_rtol; p->last_reach = -1.0;
+    // a priori the subspace (1.5 x the eigenvalue count is the usual M0) reaches about 1.4 half widths
+    p->aspect = p->steer ? fh_policy::pick(Emin, Emax, ne, quadrature, inner_rtol, p->cap, 1.4, nullptr, 0, 0) : fpm18;
+    return 0;
+}
+
+extern "C" int feasthip_policy_update(feasthip_policy* p, double epsout, int M, int any_node_capped, const double* ritz, int nritz) {
+    if (!p || (nritz > 0 && !ritz) || M < 0 || M > nritz) return FEASTHIP_ERROR_FPM;
+    // stagnation guard: the outer residual should contract by about inner_rtol per loop.  When it has not even halved over
+    // two loops the inner solves are not delivering (iteration cap too low for this matrix): double the cap
+    if (p->n_hist < 3) p->eps_hist[p->n_hist++] = epsout;
+    else { p->eps_hist[0] = p->eps_hist[1]; p->eps_hist[1] = p->eps_hist[2]; p->eps_hist[2] = epsout; }
+    if (p->n_hist >= 3 && p->eps_hist[2] > 0.5 * p->eps_hist[0] && p->inner_cap < 16 * p->base_cap) {
+        p->inner_cap *= 2;
+        p->n_hist = 0;
+    }
+    if (p->steer) {
+        // Safeguard first.  The policy promised a contraction of max(filter ratio, inner_rtol) < 0.5 per loop.  When a loop
+        // delivers less than 0.3 there are two possible culprits: inner solves that stopped at the iteration cap before
+        // reaching inner_rtol (a taller ellipse would only HELP them -- raise the cap instead), or a filter that is too soft
+        // for this spectrum (lower the ellipse, down to the circle).
+        if (std::isfinite(p->eps_prev) && std::isfinite(epsout) && epsout > 0.3 * p->eps_prev) {
+            if (any_node_capped && p->inner_cap < 16 * p->base_cap) { p->inner_cap *= 2; p->n_hist = 0; }
+            else if (p->aspect > 100) p->cap = std::max(100, p->aspect / 2);
+        }
+        // Steering: the filter model at the reach of the subspace.  The guard Ritz values overshoot outward while they are far
+        // from converged, hence a cautious quantile of their distances early, nearly the outermost one later, and never more
+        // than double the ratio in one loop.
+        const double reach = M > 0 ? fh_policy::subspace_reach(ritz, nritz, p->Emin, p->Emax, !(epsout < 1e-2) ? 0.8 : 0.95) : -1.0;
+        p->last_reach = reach;
+        p->aspect = reach >= 0.0 ? fh_policy::pick(p->Emin, p->Emax, p->ne, p->quadrature, p->inner_rtol, p->cap, reach, ritz, M, 2 * p->aspect)
+                                 : std::min(p->aspect, p->cap);
+    }
+    // The last loop: a sweep reduces the outer residual by about 2 x its inner tolerance; when less than that is still
+    // needed to reach outer_tol, the next sweep's inner tolerance is relaxed to what is needed (with a margin of 3), never
+    // beyond 0.3 -- on cfg 3 a loop that starts at 1.3e-12 for a target of 1e-12 costs a third of a full one
+    p->next_rtol = p->inner_rtol;
+    if (p->outer_tol > 0.0 && std::isfinite(epsout) && epsout > p->outer_tol)
+        p->next_rtol = std::min(0.3, std::max(p->inner_rtol, 0.32 * p->outer_tol / epsout));
+    p->eps_prev = epsout;
+    return 0;
+}
+
+extern "C" int feasthip_policy_set_aside(const double* res, int M, int* flags) {
+    // Inexact inner solves leave solver noise in the guard columns.  Its Ritz values are arbitrary; one that lands inside
+    // the interval has an O(1) residual that never contracts and would hold epsout up forever (variant A has no
+    // spurious-pair removal; with exact solves the guard columns are true eigen-directions and stay outside).  A pair is set
+    // aside when its relative residual is > 0.1 AND > 100x the smallest residual of the pairs inside: a true pair inside the
+    // interval sees a filter value >= 1/2 and contracts with the others.
+    if (!res || !flags || M <= 1) { if (flags) for (int j = 0; j < M; ++j) flags[j] = 0; return 0; }
+    double rmin = res[0];
+    for (int j = 1; j < M; ++j) rmin = std::min(rmin, res[j]);
+    int n = 0;
+    for (int j = 0; j < M; ++j) { flags[j] = (res[j] > 0.1 && res[j] > 100.0 * rmin) ? 1 : 0; n += flags[j]; }
+    if (n == 0 || n >= M) { for (int j = 0; j < M; ++j) flags[j] = 0; return 0; }
+    return n;
+}
+
+extern "C" double feasthip_policy_filter_ratio(double Emin, double Emax, int ne, int quadrature, int fpm18, double reach,
+                                               const double* inside, int n_inside) {
+    if (!(Emax > Emin) || ne < 1 || fpm18 < 0 || (quadrature != 0 && quadrature != 1)) return NAN;
+    return fh_policy::filter_ratio(Emin, Emax, ne, quadrature, fpm18, reach, inside, n_inside);
+}
+
+extern "C" double feasthip_policy_reach(const double* ritz, int n, double Emin, double Emax, double quantile) {
+    if (n > 0 && !ritz) return -1.0;
+    return fh_policy::subspace_reach(ritz, n, Emin, Emax, quantile);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -8,10 +8,11 @@
 // RCCL (PyTorch bundles one) shares it and a Julia host picks up /opt/rocm/lib/librccl.so; one rank per GPU,
 // ncclAllReduce(SUM, f64) on the handle's stream over xGMI.
 // Transport 2 ("shm"): ranks that SHARE a device (RCCL refuses two ranks of one communicator on one HIP
-// device: "Duplicate GPU detected"), used by test rigs that rehearse N ranks on one card.  Rendezvous through a
-// POSIX shared-memory segment named after the unique id; every rank exports a staging buffer with
-// hipIpcGetMemHandle, peers map it, and a kernel sums the staged buffers in RANK ORDER (bitwise identical on
-// every rank).  Host-synchronous by design; it is a rehearsal transport, not the fast path.
+// device: "Duplicate GPU detected"), used by test rigs that rehearse N ranks on one card -- as processes, as threads of one
+// process (one handle per thread), or a mix.  Rendezvous through a POSIX shared-memory segment named after the unique id;
+// every rank exports a staging buffer with hipIpcGetMemHandle, peers of other processes map it (peers of the same process
+// take its pointer), and a kernel sums the staged buffers in RANK ORDER (bitwise identical on every rank).  Host-synchronous
+// by design; it is a rehearsal transport, not the fast path.
 #include "fh_common.hpp"
 #include "fh_comm.hpp"
 #include "../../include/feasthip.h"
@@ -82,6 +83,10 @@ struct shm_segment {
     std::atomic<unsigned> failed;                    // a rank hit an error: everybody leaves the barrier
     hipIpcMemHandle_t handle[FH_SHM_MAX_RANKS];
     unsigned long long bytes[FH_SHM_MAX_RANKS];
+    // ranks may also be THREADS of one process (one handle per thread): a peer of the same process is reached through
+    // its device pointer, hipIpcOpenMemHandle refuses a handle exported by the opening process itself
+    long long pid[FH_SHM_MAX_RANKS];
+    unsigned long long ptr[FH_SHM_MAX_RANKS];
 };
 
 uint64_t fnv1a(const char* p, size_t n) {
@@ -100,6 +105,7 @@ struct fh_comm {
     unsigned sense = 0;
     void* staging = nullptr; size_t staging_bytes = 0;
     void* peer[FH_SHM_MAX_RANKS] = {nullptr};
+    bool peer_ipc[FH_SHM_MAX_RANKS] = {false};       // mapped with hipIpcOpenMemHandle (to be closed), not a same-process pointer
     const double** d_peers = nullptr;                // device array of the mapped peer pointers
     double timeout_s = 120.0;
 };
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(256) void k_sum_peers(const double* const* __restri
 
 static void shm_unmap_peers(fh_comm* c) {
     for (int r = 0; r < c->nranks; ++r) {
-        if (c->peer[r] && r != c->rank) hipIpcCloseMemHandle(c->peer[r]);
-        c->peer[r] = nullptr;
+        if (c->peer[r] && c->peer_ipc[r]) hipIpcCloseMemHandle(c->peer[r]);
+        c->peer[r] = nullptr; c->peer_ipc[r] = false;
     }
 }
 
@@ -154,11 +160,18 @@ static int shm_setup_staging(feasthip_ctx* h, fh_comm* c) {
     if (e != hipSuccess) return fail(std::string("comm(shm): hipIpcGetMemHandle: ") + hipGetErrorString(e) +
                                      " (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set for dmabuf IPC)");
     c->seg->bytes[c->rank] = cap;
+    c->seg->pid[c->rank] = (long long)getpid();
+    c->seg->ptr[c->rank] = (unsigned long long)(uintptr_t)c->staging;
     if (!shm_barrier(c)) { h->last_error = "comm(shm): peers did not publish their staging buffers"; return FEASTHIP_ERROR_INTERNAL; }
     for (int r = 0; r < c->nranks; ++r) {
         if (r == c->rank) { c->peer[r] = c->staging; continue; }
-        e = hipIpcOpenMemHandle(&c->peer[r], c->seg->handle[r], hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return fail(std::string("comm(shm): hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        if (c->seg->pid[r] == (long long)getpid()) {
+            c->peer[r] = (void*)(uintptr_t)c->seg->ptr[r];        // a thread of this process: same address space
+        } else {
+            e = hipIpcOpenMemHandle(&c->peer[r], c->seg->handle[r], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return fail(std::string("comm(shm): hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+            c->peer_ipc[r] = true;
+        }
         c->staging_bytes = std::min<size_t>(c->staging_bytes, (size_t)c->seg->bytes[r]);
     }
     e = hipMalloc((void**)&c->d_peers, FH_SHM_MAX_RANKS * sizeof(double*));

@@ -30,8 +30,8 @@ import time
 import numpy as np
 import scipy.linalg as sla
 
-from .contour import (balanced_contour_points, choose_aspect, cost_balanced_contour_points, distribute_contour_points, feast_contour,
-                      feast_gcontour, feast_inside_gcontour, split_balanced_assignment, subspace_reach)
+from .contour import (balanced_contour_points, cost_balanced_contour_points, distribute_contour_points, feast_contour,
+                      feast_gcontour, feast_inside_gcontour, split_balanced_assignment)
 from .parameters import check_feast_srci_input, feast_tolerance, feastdefault
 from .types import FeastError, FeastResult
 
@@ -186,11 +186,11 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
       eigenpairs, many more refinement loops.
     contour_policy: None keeps fpm[18] as given (the reference's behaviour).  "auto" (inexact iterative solves with the
       real projection only; ignored otherwise) lets the driver pick the ellipse ratio fpm[18] itself, loop by loop
-      (contour.choose_aspect): with inner solves that reduce the residual by inner_rtol per loop the contraction of a
+      (feasthip_policy_*, csrc/fh_policy.hpp): with inner solves that reduce the residual by inner_rtol per loop the contraction of a
       refinement loop is max(filter ratio, ~2 inner_rtol), so among the candidate ratios the one minimising the
       predicted work  a^-0.6 / ln(1 / max(filter ratio(a), inner_rtol))  is taken (a^-0.6: measured fall of the
       Krylov iterations per loop with the ratio a; a taller ellipse moves every node away from the spectrum).  The
-      filter ratio is evaluated at the reach of the current subspace (contour.subspace_reach of the Ritz values; loop 0:
+      filter ratio is evaluated at the reach of the current subspace (feasthip_policy_reach of the Ritz values; loop 0:
       the a-priori 1.4 half widths of a subspace 1.5 times the eigenvalue count).  Safeguard: when a loop contracts
       the residual by less than 0.3 although the policy promised better, then -- if inner solves stopped at the iteration
       cap -- the cap is doubled, else the ratio is halved for the next loops, down to the reference's circle.
@@ -274,47 +274,53 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                               factor_precision=32, cache_factors=True)
         else:
             raise ValueError("inner_precision=32 needs a direct solver or the warm-started inexact iterative mode")
-    # -- contour policy (see the docstring): only where the filter is the real-projection filter and the solves are inexact
+    # -- the host policy of the inexact mode (contour steering, iteration-cap guards, last-loop tolerance) lives under the C
+    #    ABI: feasthip_policy_* (csrc/fh_policy.hpp).  Steering only where the filter is the real-projection filter.
     auto_contour = bool(contour_policy == "auto" and contour is None and inexact and real_projection and int(fpm[16]) in (0, 1))
-    policy = {"aspect": int(fpm[18]), "cap": 8000, "history": []}
-
-    def policy_pick(d_rel, inside_ritz=None, limit=None):
-        """fpm[18] minimising the predicted work at subspace reach d_rel (capped by the safeguard and by `limit`)."""
-        from .contour import ASPECT_CANDIDATES, filter_ratio
-        floor_c = float(inner_rtol)
-        best, best_cost = 100, None
-        for a in ASPECT_CANDIDATES:
-            if a > policy["cap"] or (limit is not None and a > limit):
-                continue
-            c = max(filter_ratio(Emin, Emax, int(fpm[2]), int(fpm[16]), a, d_rel, inside_ritz), floor_c)
-            if c >= 0.5:
-                continue
-            cost = a ** -0.6 / math.log(1.0 / c)
-            if best_cost is None or cost < best_cost:
-                best, best_cost = a, cost
-        return int(best)
-
-    if auto_contour:
+    pol = None
+    policy_hist, policy_reach = [], []
+    if inexact:
+        import ctypes as _C
+        from . import _lib as _libmod
+        _plib = _libmod.load_library()
+        pol = _libmod.FeastHipPolicy()
+        rcp = _plib.feasthip_policy_init(_C.byref(pol), float(Emin), float(Emax), int(fpm[2]), int(fpm[16]), float(inner_rtol),
+                                         float(max(feast_tolerance(fpm), float(eps_floor))), int(solver_maxiter), int(auto_contour), int(fpm[18]))
+        if rcp != 0:
+            pol = None
+    if auto_contour and pol is not None:
         fpm = fpm.copy()
-        fpm[18] = policy["aspect"] = policy_pick(1.4)
+        fpm[18] = int(pol.aspect)
         Zne, Wne = feast_contour(Emin, Emax, fpm)
         engine.set_contour(Zne, Wne, 2.0)
         engine.set_node_list(local_nodes)         # set_contour resets the node selection to "all"
-        policy["history"].append(policy["aspect"])
+        policy_hist.append(int(pol.aspect))
     t_setup = time.perf_counter() - t_setup
 
     if Q0 is not None and hasattr(Q0, "data_ptr"):
-        dQ = Q0.clone()                           # initial subspace already resident on the device (M0 x N)
+        dQ = Q0                                   # initial subspace already resident on the device (M0 x N); only ever read
+    elif Q0 is None:
+        # the seeded start block is a function of (N, M0, seed): generating it on the host takes 35 ms at N = 50 000, M0 = 64 --
+        # a sixth of a default feast() call -- so an engine keeps the last one on the device for repeated calls
+        key = (int(N), int(M0), int(seed))
+        cache = getattr(engine, "_seed_cache", None)
+        if cache is not None and cache[0] == key:
+            dQ = cache[1]
+        else:
+            dQ = engine.upload(seeded_subspace(N, M0, seed))
+            try:
+                engine._seed_cache = (key, dQ)
+            except AttributeError:
+                pass
     else:
-        Q_host = seeded_subspace(N, M0, seed) if Q0 is None else np.asarray(Q0, dtype=np.complex128)
-        dQ = engine.upload(Q_host)
+        dQ = engine.upload(np.asarray(Q0, dtype=np.complex128))
     maxloop = int(fpm[4])
     eps_tol = max(feast_tolerance(fpm), float(eps_floor))      # eps_floor: sqrt(eps(Float32)) for single-precision callers
     epsout, info, loop_count, M_found, active = math.inf, 0, 0, 0, M0
     lam_vec = np.zeros(M0)
     res_vec = np.zeros(M0)
     ritz_lambda = None
-    eps_hist, inner_cap = [], int(solver_maxiter)
+    inner_cap, loop_rtol = int(solver_maxiter), (float(inner_rtol) if inner_rtol is not None else None)
     dX = None
     stats = {"setup_seconds": t_setup, "krylov_iterations": 0, "spmm_calls": 0, "factorizations": 0,
              "solve_seconds": 0.0, "loops": [], "node_iterations": [], "node_lists": [], "local_nodes": [int(v) for v in local_nodes], "phase_seconds": {"apply": 0.0, "reduce": 0.0, "ortho": 0.0,
@@ -478,8 +484,11 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                 # with the others, it cannot sit at 10 % while another pair is 100x ahead.  Set-aside pairs stay in the
                 # subspace and are re-examined every loop (measured on a random pencil: the ten true pairs contract by
                 # ~1e-2 per loop while one to three noise pairs stay at residual 1).
-                flag = (res > 0.1) & (res > 100.0 * float(res.min()))
-                n_spurious = int(flag.sum())
+                import ctypes as _C
+                resc = np.ascontiguousarray(res, dtype=np.float64)
+                flags_i = np.zeros(M, dtype=np.int32)
+                n_spurious = int(_plib.feasthip_policy_set_aside(resc.ctypes.data_as(_C.c_void_p), int(M), flags_i.ctypes.data_as(_C.c_void_p)))
+                flag = flags_i.astype(bool)
                 if 0 < n_spurious < M:
                     order = np.concatenate([np.nonzero(~flag)[0], np.nonzero(flag)[0], np.arange(M, rank_q)])
                     lam_sorted = lam_sorted[order]
@@ -515,57 +524,34 @@ def feast_hip_hermitian(engine, A, B, Emin, Emax, M0, fpm, *, freeze_guards_afte
                 info = int(FeastError.Feast_ERROR_NO_CONVERGENCE)
                 stats["aborted"] = True
                 break
-            if inexact:
-                # stagnation guard: the outer residual should contract by about inner_rtol per loop.  When it has not even
-                # halved over two loops the inner solves are not delivering (iteration cap too low for this matrix):
-                # double the cap (cfg 3 contracts by 0.03-0.1 per loop and never gets here)
-                eps_hist.append(epsout)
-                if len(eps_hist) >= 3 and eps_hist[-1] > 0.5 * eps_hist[-3] and inner_cap < 16 * solver_maxiter:
-                    inner_cap *= 2
-                    engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
+            if pol is not None:
+                # one call decides the next sweep: iteration cap (stagnation guard; capped nodes under the contour policy), inner
+                # tolerance (relaxed when the outer tolerance is within reach), and -- under the contour policy -- fpm[18]
+                import ctypes as _C
+                ritz_c = np.ascontiguousarray(lam_sorted[:rank_q], dtype=np.float64)
+                prev_aspect, prev_cap, prev_rtol = int(pol.aspect), int(pol.inner_cap), float(pol.next_rtol)
+                _plib.feasthip_policy_update(_C.byref(pol), float(epsout), int(M), int(int(np.max(status)) == 5),
+                                             ritz_c.ctypes.data_as(_C.c_void_p), int(rank_q))
+                if int(pol.inner_cap) != prev_cap or float(pol.next_rtol) != prev_rtol:
+                    inner_cap, loop_rtol = int(pol.inner_cap), float(pol.next_rtol)
+                    engine.set_solver(solver, rtol=loop_rtol, atol=0.0, maxit=inner_cap, restart=solver_restart,
                                       factor_precision=inner_precision)
-                    stats["inner_cap"] = inner_cap
-                    eps_hist.clear()
-            if auto_contour:
-                # Safeguard first.  The policy promised a contraction of max(filter ratio, inner_rtol) < 0.5 per loop.  When a
-                # loop delivers less than 0.3 there are two possible culprits: inner solves that stopped at the iteration
-                # cap before reaching inner_rtol (status 5 on some node: a taller ellipse would only HELP them -- raise the
-                # cap instead), or a filter that is too soft for this spectrum (lower the ellipse, down to the circle).
-                prev = stats["loops"][-2]["epsout"] if len(stats["loops"]) >= 2 else math.inf
-                if math.isfinite(prev) and math.isfinite(epsout) and epsout > 0.3 * prev:
-                    if int(np.max(status)) == 5 and inner_cap < 16 * solver_maxiter:
-                        inner_cap *= 2
-                        engine.set_solver(solver, rtol=float(inner_rtol), atol=0.0, maxit=inner_cap, restart=solver_restart,
-                                          factor_precision=inner_precision)
+                    if inner_cap != int(solver_maxiter):
                         stats["inner_cap"] = inner_cap
-                        eps_hist.clear()
-                    elif policy["aspect"] > 100:
-                        policy["cap"] = max(100, policy["aspect"] // 2)
-                # Steering: the filter model evaluated at the reach of the subspace.  The guard Ritz values overshoot outward
-                # while they are far from converged (measured on four 50 000-unknown pencils: apparent reach 5-15 half widths
-                # after loop 0, 2-4 while the wanted pairs pass 1e-3, within 2 % of the first eigenvalue outside the subspace
-                # late), hence a cautious quantile of their distances early, nearly the outermost one later, and never more
-                # than double the ratio in one loop.  Five steering rules were measured on those pencils (this one; the same
-                # gated on epsout < 1e-2; outermost guard with one notch per loop; acting only on a reach that two loops
-                # agree on; a feedback rule on the observed contraction): all land within 10 % of each other and 3-9 times
-                # ahead of the circle -- the early over-estimates cost little because an early loop on a taller ellipse is
-                # also a cheaper loop; this rule had the best geometric mean.
-                reach = subspace_reach(lam_sorted[:rank_q], Emin, Emax, 0.8 if not (epsout < 1e-2) else 0.95) if M > 0 else None
-                want = (policy_pick(reach, lam_sorted[:M], limit=2 * policy["aspect"]) if reach is not None
-                        else min(policy["aspect"], policy["cap"]))
-                if want != policy["aspect"]:
-                    fpm[18] = policy["aspect"] = want
-                    Zne, Wne = feast_contour(Emin, Emax, fpm)
-                    engine.set_contour(Zne, Wne, 2.0)
-                    engine.set_node_list(local_nodes)
-                policy["history"].append(policy["aspect"])
-                policy.setdefault("reach", []).append(None if reach is None else round(reach, 3))
+                if auto_contour:
+                    if int(pol.aspect) != prev_aspect:
+                        fpm[18] = int(pol.aspect)
+                        Zne, Wne = feast_contour(Emin, Emax, fpm)
+                        engine.set_contour(Zne, Wne, 2.0)
+                        engine.set_node_list(local_nodes)
+                    policy_hist.append(int(pol.aspect))
+                    policy_reach.append(None if pol.last_reach < 0 else round(float(pol.last_reach), 3))
             active = rank_q
             dQ = dX                                   # Q_basis[:, 1:rank] = solutions[:, 1:rank]
             ritz_lambda = lam_sorted.copy()
 
-    if auto_contour:
-        stats["contour_policy"] = {"fpm18_per_loop": policy["history"], "cap": policy["cap"], "reach": policy.get("reach")}
+    if auto_contour and pol is not None:
+        stats["contour_policy"] = {"fpm18_per_loop": policy_hist, "cap": int(pol.cap), "reach": policy_reach}
     if hasattr(engine, "set_column_mask"):
         engine.set_column_mask(None)
     if M_found == 0 and info == 0:

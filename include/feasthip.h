@@ -208,6 +208,40 @@ int  feasthip_band_plan(feasthip_handle h, int* kl, int* ku, int64_t* bytes_per_
 int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit,
                          int restart, int factor_precision, int cache_factors);
 
+/* ---- host policy of the inexact FEAST mode (no device work; needs no problem and no GPU) -----------------------------
+ * What the :hip backend adds to the reference's driver loop when `solver = :direct` on large sparse input is served by the
+ * warm-started, inexact Krylov sweeps (not in the reference; DESIGN.md sections 2 and 5): which ellipse ratio fpm[18] to put
+ * the Gauss / trapezoid nodes on, how many inner iterations and which inner tolerance the next sweep gets, and which Ritz
+ * pairs are solver noise.  Kept here so that a host shim CALLS it instead of re-porting it:
+ *   feasthip_policy_init     state for one solve.  steer != 0: the library picks fpm[18] itself (the caller left it unset),
+ *                            p->aspect holds the a-priori choice; steer == 0: p->aspect = fpm18 stays, only the guards act.
+ *   feasthip_policy_update   after every refinement loop that did not converge: epsout, the count M of Ritz values inside,
+ *                            whether a node stopped at the iteration cap (node_status 5), the rank Ritz values ordered
+ *                            inside-first.  On return p->aspect (changed: recompute the contour with it, feasthip_set_contour),
+ *                            p->inner_cap and p->next_rtol (feasthip_set_solver) describe the NEXT sweep.
+ *   feasthip_policy_set_aside  flags[j] = 1 for pairs inside the interval that are solver noise (residual > 0.1 and > 100 x
+ *                            the smallest residual inside); returns their number (0 when all M would be flagged).
+ *   feasthip_policy_filter_ratio / _reach: the filter model the steering rests on (for tests and diagnostics).        */
+typedef struct feasthip_policy {
+    double Emin, Emax, inner_rtol, outer_tol;
+    int ne, quadrature;          /* fpm[2], fpm[16] (0 Gauss, 1 trapezoid)                                              */
+    int steer;                   /* 1: the policy picks fpm[18]; 0: guards only                                          */
+    int aspect, cap;             /* fpm[18] of the next sweep; upper bound the safeguard has put on it (8000 at first)  */
+    int inner_cap, base_cap;     /* Krylov iteration cap per loop: next sweep / as given                                */
+    int n_hist;
+    double eps_prev;             /* outer residual of the previous loop (inf before the first)                          */
+    double eps_hist[3];          /* stagnation guard                                                                    */
+    double next_rtol;            /* inner relative tolerance of the next sweep                                          */
+    double last_reach;           /* subspace reach the last update steered by (< 0: none)                               */
+} feasthip_policy;
+int    feasthip_policy_init(feasthip_policy* p, double Emin, double Emax, int ne, int quadrature, double inner_rtol,
+                            double outer_tol, int solver_maxiter, int steer, int fpm18);
+int    feasthip_policy_update(feasthip_policy* p, double epsout, int M, int any_node_capped, const double* ritz, int nritz);
+int    feasthip_policy_set_aside(const double* res, int M, int* flags);
+double feasthip_policy_filter_ratio(double Emin, double Emax, int ne, int quadrature, int fpm18, double reach,
+                                    const double* inside, int n_inside);
+double feasthip_policy_reach(const double* ritz, int n, double Emin, double Emax, double quantile);
+
 /* ---- the hot path ------------------------------------------------------------------ */
 /* One contour sweep over this handle's node range:
  *     for e in local nodes:  Y_e = (z_e B - A)^{-1} (B Q);   Qproj += weight_scale*w_e*Y_e

@@ -467,39 +467,90 @@ def test_split_balanced_assignment_covers_every_node_column_pair_once():
 
 
 def test_contour_policy_filter_model():
-    """contour.filter_values / filter_ratio / choose_aspect / subspace_reach: the filter of the half contour with the real
-    projection is ~1 inside, 1/2 at the interval ends, decays outside; it is invariant under shift and scaling of the
-    interval; the envelope ratio falls with the distance and rises with the ellipse ratio."""
+    """The filter model of the policy, in the LIBRARY (feasthip_policy_filter_ratio / _reach through contour.filter_ratio /
+    subspace_reach) against its numpy restatement (tests/policy_reference.py): the filter of the half contour with the real
+    projection is ~1 inside, 1/2 at the interval ends, decays outside; the envelope ratio is invariant under shift and
+    scaling of the interval, falls with the distance and rises with the ellipse ratio."""
+    import policy_reference as pr
     from feastkit_jl_amd import contour as ct
     fpm = fk.feastinit(); fpm[2] = 16
     fk.feastdefault(fpm)
     Z, W = fk.feast_contour(2.0, 6.0, fpm)
-    f = ct.filter_values(Z, W, np.array([2.0, 3.0, 4.0, 5.5, 6.0, 6.6, 8.0, 20.0, -3.0]))
+    f = pr.filter_values(Z, W, np.array([2.0, 3.0, 4.0, 5.5, 6.0, 6.6, 8.0, 20.0, -3.0]))
     assert np.allclose(f[[1, 2, 3]], 1.0, atol=1e-6) and np.allclose(f[[0, 4]], 0.5, atol=1e-6)
     assert abs(f[5]) < 1e-3 and abs(f[6]) < 1e-8 and abs(f[7]) < 1e-12 and abs(f[8]) < 1e-10
+    # library == restatement over ratios, quadratures, node counts, distances, with and without Ritz values inside
+    rng = np.random.default_rng(1)
+    for ne in (8, 16, 24):
+        for q in (0, 1):
+            for a in (100, 300, 1600, 4000, 8000):
+                for d in (1.0, 1.2, 1.5, 2.5, 7.0):
+                    ins = None if rng.random() < 0.5 else np.sort(rng.uniform(2.0, 6.0, 9))
+                    lib, ref = ct.filter_ratio(2.0, 6.0, ne, q, a, d, ins), pr.filter_ratio(2.0, 6.0, ne, q, a, d, ins)
+                    assert abs(lib - ref) <= 1e-6 * ref + 1e-14, (ne, q, a, d, lib, ref)
     # scale / shift invariance of the ratio, monotone in the distance, growing with the ellipse ratio
     for a in (100, 800, 4000):
         r1 = ct.filter_ratio(2.0, 6.0, 16, 0, a, 1.5)
         r2 = ct.filter_ratio(-0.3, 0.1, 16, 0, a, 1.5)
-        assert abs(r1 / r2 - 1.0) < 1e-9
+        assert abs(r1 / r2 - 1.0) < 1e-6
         assert ct.filter_ratio(2.0, 6.0, 16, 0, a, 1.2) >= r1 >= ct.filter_ratio(2.0, 6.0, 16, 0, a, 2.5)
     assert ct.filter_ratio(0, 1, 16, 0, 100, 1.5) < ct.filter_ratio(0, 1, 16, 0, 800, 1.5) < ct.filter_ratio(0, 1, 16, 0, 8000, 1.5)
     # the envelope is an upper bound of the filter beyond d
     fpm[18] = 2400
     Z, W = fk.feast_contour(0.0, 2.0, fpm)
     lam = 1.0 + np.linspace(1.5, 40.0, 3000)
-    inn = np.abs(ct.filter_values(Z, W, np.linspace(0.0, 2.0, 65))).min()
-    assert np.abs(ct.filter_values(Z, W, lam)).max() / inn <= ct.filter_ratio(0.0, 2.0, 16, 0, 2400, 1.5) * (1 + 1e-6)
-    # choose_aspect: the tallest candidate under the target; the circle when nothing qualifies
-    a = ct.choose_aspect(0.0, 1.0, 16, 0, 1.5, 0.06)
-    assert a >= 1600 and ct.filter_ratio(0.0, 1.0, 16, 0, a, 1.5) <= 0.06
-    assert ct.choose_aspect(0.0, 1.0, 16, 0, 1.5, 1e-12) == 100
-    assert ct.choose_aspect(0.0, 1.0, 16, 0, 1.1, 0.03) < ct.choose_aspect(0.0, 1.0, 16, 0, 2.0, 0.03)
+    inn = np.abs(pr.filter_values(Z, W, np.linspace(0.0, 2.0, 65))).min()
+    assert np.abs(pr.filter_values(Z, W, lam)).max() / inn <= ct.filter_ratio(0.0, 2.0, 16, 0, 2400, 1.5) * (1 + 1e-6)
     # subspace_reach: guards only, measured from the midpoint in half widths
     ritz = np.array([0.2, 0.5, 0.9, 1.3, 1.6, -0.4, 2.0])
-    assert ct.subspace_reach(ritz, 0.0, 1.0, 1.0) == pytest.approx(3.0)
-    assert ct.subspace_reach(ritz, 0.0, 1.0, 0.0) == pytest.approx(1.6)
+    assert ct.subspace_reach(ritz, 0.0, 1.0, 1.0) == pytest.approx(3.0) == pr.subspace_reach(ritz, 0.0, 1.0, 1.0)
+    assert ct.subspace_reach(ritz, 0.0, 1.0, 0.0) == pytest.approx(1.6) == pr.subspace_reach(ritz, 0.0, 1.0, 0.0)
     assert ct.subspace_reach(np.array([0.2, 0.5]), 0.0, 1.0) is None
+
+
+def test_policy_state_machine_matches_reference():
+    """feasthip_policy_init / _update / _set_aside (the C ABI's copy of the inexact-mode policy) against the numpy
+    restatement over random trajectories: the same fpm[18], iteration cap and inner tolerance after every loop."""
+    import ctypes as C
+    import policy_reference as pr
+    from feastkit_jl_amd import _lib
+    lib = fk.load_library()
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        Emin = float(rng.uniform(-2, 2)); Emax = Emin + float(rng.uniform(0.1, 3.0))
+        ne, q = int(rng.choice([8, 12, 16])), int(rng.choice([0, 1]))
+        rt, tol, cap0, steer = float(rng.choice([3e-2, 1e-2, 1e-1])), 1e-12, int(rng.choice([50, 100])), int(rng.random() < 0.8)
+        pol = _lib.FeastHipPolicy()
+        assert lib.feasthip_policy_init(C.byref(pol), Emin, Emax, ne, q, rt, tol, cap0, steer, 100) == 0
+        ref = pr.PolicyReference(Emin, Emax, ne, q, rt, tol, cap0, steer, 100)
+        assert pol.aspect == ref.aspect and pol.inner_cap == ref.inner_cap
+        eps = float(rng.uniform(0.05, 1.0))
+        r, mid = 0.5 * (Emax - Emin), 0.5 * (Emax + Emin)
+        for loop in range(14):
+            M = int(rng.integers(0, 20))
+            inside = np.sort(rng.uniform(Emin, Emax, M))
+            guards = mid + rng.choice([-1, 1], 12) * r * rng.uniform(1.05, 6.0 if loop < 3 else 2.0, 12)
+            ritz = np.concatenate([inside, guards])
+            capped = int(rng.random() < 0.3)
+            eps *= float(rng.choice([0.03, 0.05, 0.2, 0.6, 0.9, 1.2]))
+            rc = lib.feasthip_policy_update(C.byref(pol), eps, M, capped, ritz.ctypes.data_as(C.c_void_p), len(ritz))
+            ref.update(eps, M, capped, ritz)
+            assert rc == 0 and (pol.aspect, pol.inner_cap, pol.cap) == (ref.aspect, ref.inner_cap, ref.cap), (trial, loop)
+            assert pol.next_rtol == pytest.approx(ref.next_rtol, rel=1e-14)
+    # the last loop: 1.3e-12 for a target of 1e-12 relaxes the inner tolerance; 1.7e-11 does not
+    pol = _lib.FeastHipPolicy()
+    lib.feasthip_policy_init(C.byref(pol), 0.0, 1.0, 16, 0, 3e-2, 1e-12, 50, 0, 4000)
+    z = np.zeros(1)
+    lib.feasthip_policy_update(C.byref(pol), 1.7e-11, 0, 0, z.ctypes.data_as(C.c_void_p), 0)
+    assert pol.next_rtol == 3e-2 and pol.aspect == 4000
+    lib.feasthip_policy_update(C.byref(pol), 1.3e-12, 0, 0, z.ctypes.data_as(C.c_void_p), 0)
+    assert 0.2 < pol.next_rtol <= 0.3
+    # set-aside rule
+    res = np.array([1e-6, 2e-6, 0.9, 3e-6, 0.4])
+    flags = np.zeros(5, dtype=np.int32)
+    assert lib.feasthip_policy_set_aside(res.ctypes.data_as(C.c_void_p), 5, flags.ctypes.data_as(C.c_void_p)) == 2 and flags.tolist() == [0, 0, 1, 0, 1]
+    res = np.array([0.5, 0.9, 0.7])                     # nothing converged yet: nobody is 100x ahead
+    assert lib.feasthip_policy_set_aside(res.ctypes.data_as(C.c_void_p), 3, flags.ctypes.data_as(C.c_void_p)) == 0 and flags[:3].tolist() == [0, 0, 0]
 
 
 def test_contour_policy_driver_host_logic():
