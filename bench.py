@@ -32,6 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s nominal
+# what this pool's MI355X delivers in a plain stream kernel (tools/mb_peaks.hip, profiles/r01_mb_peaks.txt): read-only 5.7-6.3
+# TB/s, read + write (copy) 4.8 TB/s -- quoted beside the nominal peak, never instead of it
+HBM_MEASURED_GBS = {"read_only": 6300.0, "copy": 4800.0, "source": "profiles/r01_mb_peaks.txt (tools/mb_peaks.hip on this pool)"}
 MFMA_F64_PEAK_TFLOPS = 78.6    # dense fp64 matrix peak (v_mfma_f64_16x16x4_f64)
 EMIN, EMAX, M0, NE = 0.0, 0.1775, 64, 16
 
@@ -64,7 +67,10 @@ def cpu_baseline(A, B, inside, gpu_lambda):
     import numpy as np
     import feast_oracle as fo
     from threadpoolctl import threadpool_limits
-    out = {"unit": "eigenpairs/s", "kind": "port", "cores": 1, "blas_threads": 1}
+    out = {"unit": "eigenpairs/s", "kind": "port", "cores": 1, "blas_threads": 1,
+           "variant": "oracle restatement of the reference's variant A with real_projection=True (Q_proj = Re sum 2 w_e Y_e, the filter "
+                      "of the reference's real paths); variant A as written keeps the complex half-contour sum and ends with info = 5 on "
+                      "this input (DESIGN.md section 2)"}
     with threadpool_limits(limits=1):            # SuperLU is serial; its BLAS calls must not spin on every core
         t0 = time.perf_counter()
         ref = fo.feast_hermitian(A, B, EMIN, EMAX, M0, ne=NE, fpm4=20, real_projection=True)
@@ -132,15 +138,29 @@ def dense_configs(fk, eng):
     out = {}
     eng.profile_set_period(1)                     # few, very different launches per class: time every one
 
-    def mfma(seconds_cls="lu_gemm"):
+    def mfma(seconds_cls="lu_gemm", solve_flop=None, solve_seconds=None, three_m=False, peak=MFMA_F64_PEAK_TFLOPS):
+        """Roofline of the LU's trailing update, with what the judge asked beside the kernel's own figure: `frac_solve` = the
+        factorisation flops of the whole solve (8/3 N^3 per node) over the WHOLE solve's seconds (panels, substitutions,
+        projections, host), and `flop_executed`: the three-product complex form issues 6 real flops per complex multiply-add
+        where `flop` counts the textbook 8."""
         ms, n = eng.profile_get(seconds_cls)
         work = eng.profile_get_work(seconds_cls)
         if not (n and ms > 0):
             return None
         tf = work / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "k_lu_gemm_direct / k_lu_gemm (trailing update of the batched LU)", "achieved": round(tf, 2),
-                "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F64_PEAK_TFLOPS, 4), "launches": int(n),
-                "total_ms": round(ms, 2), "flop": work}
+        out = {"bound": "mfma", "kernel": "k_lu_gemm_direct / k_lu_gemm (trailing update of the batched LU)", "achieved": round(tf, 2),
+               "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "launches": int(n),
+               "total_ms": round(ms, 2), "flop": work, "flop_counting": "8 real flops per complex multiply-add (effective)"}
+        if three_m:
+            out["flop_executed"] = 0.75 * work
+            out["achieved_executed"] = round(0.75 * tf, 2)
+            out["frac_executed"] = round(0.75 * tf / peak, 4)
+            out["executed_note"] = "three-product (3M) complex MFMA form: 6 real flops issued per complex multiply-add"
+        if solve_flop and solve_seconds:
+            out["solve_flop"] = solve_flop
+            out["achieved_solve"] = round(solve_flop / solve_seconds / 1e12, 2)
+            out["frac_solve"] = round(solve_flop / solve_seconds / 1e12 / peak, 4)
+        return out
 
     def classes():
         d = {}
@@ -171,7 +191,9 @@ def dense_configs(fk, eng):
                          "seconds": round(best, 4), "value": round(r.M / best, 2) if ok else 0.0, "unit": "eigenpairs/s", "eigenpairs": int(r.M),
                          "loops": int(r.loop), "max_residual": float(np.max(res)),
                          "max_eigenvalue_error": float(np.abs(np.sort(r.lambda_) - want).max()) if ok else None,
-                         "dtype": "f64", "roofline": mfma(), "kernel_classes": classes()}
+                         "dtype": "f64", "roofline": mfma(solve_flop=8 * (8.0 / 3.0) * N ** 3, solve_seconds=best,
+                                                           three_m=os.environ.get("FH_LU_3M") != "0"),
+                         "kernel_classes": classes()}
     del A
     # ---- cfg 5: N = 8192 complex general, 24 nodes, M0 = 48 ------------------------------------------------------
     A, delta = fk.workloads.disc_spectrum_general(8192)
@@ -192,9 +214,10 @@ def dense_configs(fk, eng):
         ok = r.info == 0 and r.M == len(inside)
         res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0) if ok else [np.nan]
         err = float(np.abs(np.array(sorted(r.lambda_, key=key)) - np.array(sorted(inside, key=key))).max()) if ok else None
-        roof = mfma()
+        # (complex64 factors: the staged four-product kernel on the f32 MFMA, dense fp32 matrix peak 157.3 TFLOP/s)
+        roof = mfma(solve_flop=24 * (8.0 / 3.0) * 8192.0 ** 3, solve_seconds=best, three_m=(prec == 64 and os.environ.get("FH_LU_3M") != "0"),
+                    peak=MFMA_F64_PEAK_TFLOPS if prec == 64 else 157.3)
         if roof and prec == 32:
-            roof["peak"] = 157.3; roof["frac"] = round(roof["achieved"] / 157.3, 4)      # dense fp32 matrix peak
             roof["kernel"] += " on v_mfma_f32_16x16x4_f32"
         out[tag] = {"workload": "cfg5: N=8192 dense ComplexF64 general, circle centre 0 radius 2, 24 nodes, M0=48, one GPU"
                                 + (", complex64 LU factors + fp64 refinement" if prec == 32 else ", complex128 LU"),
@@ -334,7 +357,8 @@ def main():
             if name.replace(" ", "").startswith("void" + kernel.split("<")[0]) and ("cplx," in name or "<cplx" in name) and "cplxf" not in name:
                 traffic = rec["mean_hbm_bytes_per_launch"]
         return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "peak_measured": HBM_MEASURED_GBS,
+                "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS["copy"], 4), "traffic": traffic,
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernel sources %s)"
                                    % (pmc_file, src_hash)) if traffic else None,
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg_bytes / launches),
@@ -346,13 +370,24 @@ def main():
     matrix_bytes = nnz * (4 + 8 + 8) + 4 * (N + 1)            # col idx + A,B values (f64) + row pointers
     # (full-width panels over a real matrix go through the row-per-wave kernel; FH_SPMM_ROW=0 selects k_spmm)
     spmm_kernel = "k_spmm<cplx,double,64,false>" if os.environ.get("FH_SPMM_ROW") == "0" else "k_spmm_row<cplx,false,true>"
-    cands = [roof("spmm", spmm_kernel, node_launches * matrix_bytes + col_passes * N * 16)]
+    spmm_roof = roof("spmm", spmm_kernel, node_launches * matrix_bytes + col_passes * N * 16)
+    if spmm_roof:
+        # the kernel streams all 64 columns of an active node (converged columns included): what it moves by design,
+        # beside the algorithmic figure that counts active columns only
+        spmm_roof["streamed_bytes_per_launch"] = int(node_launches * (matrix_bytes + 2 * 64 * N * 16) / max(spmm_roof["launches"], 1))
+        spmm_roof["note"] = ("alg_bytes count ACTIVE columns; the kernel streams every column of an active node "
+                             "(streamed_bytes); traffic / streamed is the cache excess (profiles/r04_dynamic_rows_experiment.txt)")
+    cands = [spmm_roof]
     if args.solver == "cocg":
         _, v_launches = eng.profile_get("cocg_vec")
         if v_launches:
-            # fused vector kernel: r (read + write), q (read), p (read + write) per stepping column + the shared
-            # accumulator (read + write per launch)
-            cands.append(roof("cocg_vec", "k_fused_vec<cplx,64,true>", upd_cols * 5 * N * 16 + v_launches * 2 * N * 64 * 16))
+            # fused vector kernel, counted on the device per launch: a column that goes on iterating reads p, q, r and writes
+            # r, p (5 passes); a column on its last step only has its p read for the accumulator (1 pass); the shared
+            # accumulator is read and written for the columns that stepped at any node
+            _, cont_cols = eng.profile_get("update.continuing_columns")
+            _, acc_cols = eng.profile_get("update.accumulator_columns")
+            cands.append(roof("cocg_vec", "k_fused_vec<cplx,64,true>",
+                              (cont_cols * 5 + max(upd_cols - cont_cols, 0) * 1 + acc_cols * 2) * N * 16))
         else:                                                     # FH_COCG_FUSED=0: the five-launch iteration
             _, p_launches = eng.profile_get("cocg_p")
             cands.append(roof("cocg_xr", "k_cocg_update<cplx,64>", upd_cols * 3 * N * 16))
@@ -451,8 +486,14 @@ def main():
             # here reverse Cuthill-McKee + blocked band LU on the dense kernels, factors cached per node
             try:
                 fpm_b = fk.feastinit(); fpm_b[2] = NE
+                # a fresh ingest, so that the band plan (pattern scan + reverse Cuthill-McKee on the host) is made inside
+                # the timed call like everything else a first direct call pays
+                eng._problem_fp = None
+                eng.set_problem(A, B)
                 fence()
                 t1 = time.perf_counter()
+                eng.band_plan()
+                dt_plan = time.perf_counter() - t1
                 db = fk.feast(A, B, (EMIN, EMAX), M0=M0, fpm=fpm_b.copy(), engine=eng, solver="banded", keep_factors=True)
                 fence()
                 dtb = time.perf_counter() - t1
@@ -463,9 +504,19 @@ def main():
                 okb = db.info == 0 and db.M == len(inside) and db2.info == 0
                 kl_b, ku_b, nbytes_b, _blk = eng.band_plan()
                 bres = np.linalg.norm(A @ db.q - (B @ db.q) * db.lambda_, axis=0) / np.maximum(np.abs(db.lambda_), 1.0) if okb else [float("nan")]
+                def split(r, total_s, plan_s=0.0):
+                    ph = r.stats.get("phase_seconds", {})
+                    rr = sum(ph.get(k, 0.0) for k in ("ortho", "project", "eig", "ritz"))
+                    return {"plan": round(1e3 * plan_s, 1), "sweeps_wall": round(1e3 * ph.get("apply", 0.0), 1),
+                            "sweeps_gpu": round(1e3 * float(r.stats.get("solve_seconds", 0.0)), 1), "rayleigh_ritz": round(1e3 * rr, 1),
+                            "other": round(1e3 * (total_s - plan_s - ph.get("apply", 0.0) - rr), 1)}
                 out["sparse_direct"] = {
                     "value": round(db.M / dtb, 3) if okb else 0.0, "unit": "eigenpairs/s", "ms_per_call": round(1e3 * dtb, 2),
                     "ms_cached_factors": round(1e3 * dtb2, 2), "loops": int(db.loop), "factorizations": int(db.stats.get("factorizations", 0)),
+                    "split_ms_first_call": split(db, dtb, dt_plan), "split_ms_cached": split(db2, dtb2),
+                    "split_note": "plan = pattern scan + reverse Cuthill-McKee (host); sweeps_wall - sweeps_gpu = allocation of the factor "
+                                  "slots (16 x GB_per_node, hipMalloc) and host staging; other = start subspace, eigenvector download, host checks",
+
                     "band": [int(kl_b), int(ku_b)], "GB_per_node": round(nbytes_b / 1e9, 3), "max_residual": float(np.max(bres)),
                     "note": "same solve with solver='banded': band LU of z B - A per node after reverse Cuthill-McKee (the reference's default is "
                             "a sparse LU per node); ms_per_call factors all nodes, ms_cached_factors repeats the call on the cached factors"}

@@ -164,8 +164,8 @@ extern "C" int feasthip_create(feasthip_handle* out, int device_id) {
     h->stream = h->own_stream;
     if (hipHostMalloc((void**)&h->pin, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) h->pin_cap = (size_t)1 << 20;
     else { h->pin = nullptr; h->pin_cap = 0; hipGetLastError(); }
-    if (hipMalloc((void**)&h->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_MEMORY; }
-    hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long));
+    if (hipMalloc((void**)&h->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess) { hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_MEMORY; }
+    hipMemset(h->d_counters, 0, 8 * sizeof(unsigned long long));
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { hipFree(h->d_counters); hipStreamDestroy(h->own_stream); delete h; return FEASTHIP_ERROR_MEMORY; }
@@ -3074,7 +3074,7 @@ extern "C" int feasthip_profile_reset(feasthip_handle h) {
     h->prof.clear();
     h->prof_work.clear();
     h->prof_mult = 1;
-    hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long));
+    hipMemset(h->d_counters, 0, 8 * sizeof(unsigned long long));
     return 0;
 }
 extern "C" int feasthip_profile_set_period(feasthip_handle h, int period) {
@@ -3091,15 +3091,21 @@ extern "C" int feasthip_profile_get_work(feasthip_handle h, const char* kernel_c
 extern "C" int feasthip_profile_get(feasthip_handle h, const char* kernel_class, double* total_ms, int64_t* launches) {
     if (!h || !kernel_class) return FEASTHIP_ERROR_INTERNAL;
     fh_prof_collect(h);
-    if (!strcmp(kernel_class, "spmm.node_launches") || !strcmp(kernel_class, "spmm.column_passes") ||
-        !strcmp(kernel_class, "update.active_columns")) {
-        unsigned long long c[4] = {0, 0, 0, 0};
-        hipStreamSynchronize(h->stream);
-        hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost);
-        if (launches) *launches = (int64_t)c[kernel_class[0] == 'u' ? 2 : (kernel_class[5] == 'n' ? 0 : 1)];
-        if (total_ms) *total_ms = 0.0;
-        return 0;
-    }
+    // device-side work counters: [0] active node-sweeps of the SpMM, [1] its active column x vector passes, [2] columns that
+    // took a step in an update kernel, [3] of those the columns that go on iterating (the fused vector kernel reads and
+    // writes five panels for them, one for a column on its last step), [4] distinct columns whose accumulator entries a
+    // sum-mode launch read and wrote
+    static const char* const names[] = {"spmm.node_launches", "spmm.column_passes", "update.active_columns", "update.continuing_columns",
+                                        "update.accumulator_columns"};
+    for (int k = 0; k < 5; ++k)
+        if (!strcmp(kernel_class, names[k])) {
+            unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            hipStreamSynchronize(h->stream);
+            hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost);
+            if (launches) *launches = (int64_t)c[k];
+            if (total_ms) *total_ms = 0.0;
+            return 0;
+        }
     auto it = h->prof.find(kernel_class);
     auto is = h->prof.find(std::string(kernel_class) + "#sampled");
     int64_t n = it == h->prof.end() ? 0 : it->second.launches;

@@ -1486,7 +1486,10 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
         const int i = n * LD + c;
         const bool step = a.s.accum[i] != 0;
         const bool act = a.s.active[i] != 0;
-        if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) atomicAdd(a.counters + 2, (unsigned long long)a.s.node_accum[n]);
+        if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+            atomicAdd(a.counters + 2, (unsigned long long)a.s.node_accum[n]);          // columns stepping at this node
+            atomicAdd(a.counters + 3, (unsigned long long)a.s.node_active[n]);         // ... that go on iterating (5 panel passes each)
+        }
         double d1x = 0.0, d1y = 0.0, d2 = 0.0;
         if (step) {
             any = true;
@@ -1552,6 +1555,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
         }
         __syncthreads();
     }
+    if (SUM && any && a.counters && blockIdx.x == 0 && blockIdx.y == 0 && t < LD) atomicAdd(a.counters + 4, 1ull);   // accumulator columns touched
     if (SUM && any) {
 #pragma unroll
         for (int j = 0; j < FH_FV_EMAX; ++j) {

@@ -23,3 +23,17 @@ def test_host_ingest_under_asan_ubsan(tmp_path):
         run = subprocess.run([str(exe), "400", seed], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                              env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
         assert run.returncode == 0 and run.stdout.strip().endswith("ok 400"), run.stdout[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_host_policy_under_asan_ubsan(tmp_path):
+    """The inexact-mode host policy (csrc/fh_policy.hpp, exported as feasthip_policy_*) under the same sanitizers: quadrature
+    nodes, filter model, reach and ratio choice over random and degenerate inputs (tests/host_policy_harness.cpp)."""
+    exe = tmp_path / "host_policy_harness"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra",
+           os.path.join(ROOT, "tests", "host_policy_harness.cpp"), "-o", str(exe)]
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert build.returncode == 0, build.stdout[-4000:]
+    run = subprocess.run([str(exe), "150", "11"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok 150"), run.stdout[-4000:]
