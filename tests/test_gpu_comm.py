@@ -459,3 +459,82 @@ def test_rccl_two_ranks_two_gpus(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     a, b = (np.load(tmp_path / f"r{r}.npy") for r in range(2))
     assert np.array_equal(a, b)
+
+
+CPLX2 = r'''
+import os, sys, time, faulthandler
+faulthandler.dump_traceback_later(300, exit=True)
+sys.path[:0] = [r"{root}", r"{root}/oracle", r"{root}/tests"]
+import numpy as np, scipy.sparse as sp
+import feastkit_jl_amd as fk
+rank, world, out = int(sys.argv[1]), int(sys.argv[2]), r"{out}"
+eng = fk.HipEngine(0)
+uidf = os.path.join(out, "uid.bin")
+if rank == 0:
+    open(uidf + ".tmp", "wb").write(eng.comm_unique_id()); os.rename(uidf + ".tmp", uidf)
+else:
+    t0 = time.time()
+    while not os.path.exists(uidf):
+        time.sleep(0.01); assert time.time() - t0 < 120
+eng.comm_init(world, rank, open(uidf, "rb").read(), "shm")
+# complex Hermitian pencil, complex subspace: the projection keeps its imaginary part
+n, m = 1500, 40
+rng = np.random.default_rng(5)
+o1 = 0.3 * (rng.standard_normal(n - 1) + 1j * rng.standard_normal(n - 1))
+o2 = 0.1 * (rng.standard_normal(n - 7) + 1j * rng.standard_normal(n - 7))
+A = sp.csr_matrix(sp.diags([o2.conj(), o1.conj(), np.linspace(0.0, 40.0, n), o1, o2], [-7, -1, 0, 1, 7]))
+B = sp.csr_matrix(sp.diags([0.05 * np.ones(n - 1), 1.0 + 0.2 * rng.random(n), 0.05 * np.ones(n - 1)], [-1, 0, 1]).astype(np.complex128))
+Q = fk.seeded_subspace(n, m, complex_values=True)
+fpm = fk.feastinit(); fpm[2] = 8; fk.feastdefault(fpm)
+Z, W = fk.feast_contour(3.0, 4.0, fpm)
+solo = fk.HipEngine(0)
+for e in (eng, solo):
+    e.set_problem(A, B); e.set_contour(Z, W, 2.0); e.set_solver("bicgstab", rtol=1e-13, atol=0.0, maxit=6000)
+for realproj in (False, True):
+    for layout in ("columns", "nodes"):
+        for e in (eng, solo):
+            e.set_real_projection(realproj)
+        solo.set_node_range(0, len(Z))
+        dR, _, _ = solo.contour_apply(solo.upload(Q), m)
+        R = solo.download(dR, m)
+        if layout == "columns":                     # every rank sweeps all nodes for its block of columns (16 + 24)
+            eng.set_node_range(0, len(Z))
+            eng.set_column_block(0 if rank == 0 else 16, 16 if rank == 0 else m - 16)
+        else:                                       # every rank sweeps its nodes for all columns
+            first, count = fk.distribute_contour_points(len(Z), world)[rank]
+            eng.set_node_range(first, count)
+        status, _ = eng.contour_apply_resident(eng.upload(Q), m)
+        eng.set_column_block(0, -1)
+        assert int(np.max(status)) == 0
+        P = eng.download(eng.export_resident(m, which=1), m)
+        assert np.abs(P - R).max() <= 1e-9 * np.abs(R).max(), (realproj, layout, np.abs(P - R).max())
+        if not realproj:
+            assert np.abs(P.imag).max() > 1e-3 * np.abs(P).max()       # really a complex panel
+        np.save(os.path.join(out, "h%d_%d_%s.npy" % (rank, int(realproj), layout)), P)
+        # the reduction + Ritz step on the summed panel agree with the single-rank per-primitive path
+        rk, Sq, Aq = eng.rr_reduce_resident(m, 1.5e-8)
+        dRo = dR.clone()
+        assert solo.orthonormalize(dRo, m, 1.5e-8) == rk
+        S2, A2 = solo.project(dRo, rk)
+        import scipy.linalg as sla
+        assert np.abs(sla.eigh(Sq, Aq, eigvals_only=True) - sla.eigh(S2, A2, eigvals_only=True)).max() <= 1e-8
+eng.barrier(); eng.comm_destroy(); eng.close(); solo.close()
+'''
+
+
+def test_two_ranks_complex_projection_resident_sweep(tmp_path):
+    """The resident sweep under a communicator with a COMPLEX projection (complex Hermitian pencil, complex subspace: the packed
+    reduce carries interleaved complex panels) and with the real projection, by column blocks (16 + 24 of 40 columns: two
+    panel widths) and by node blocks: the summed resident Q_proj equals the single-rank sweep on both ranks, bitwise the same
+    on both, and the resident reduction on it gives the per-primitive path's Ritz values."""
+    script = tmp_path / "cplx2.py"
+    script.write_text(CPLX2.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FEASTHIP_COMM_TIMEOUT_S="120")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for rp in (0, 1):
+        for layout in ("columns", "nodes"):
+            a, b = (np.load(tmp_path / f"h{r}_{rp}_{layout}.npy") for r in range(2))
+            assert np.array_equal(a, b)
