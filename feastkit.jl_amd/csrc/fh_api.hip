@@ -672,7 +672,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     const int nblk_op = fh_op_nblk(h, ld);
     const int nblk_vec = fh_kry_nblk(N, ld, nodes);
     int fv_blk = 0, fv_seg = 0, fv_per = 0;
-    if (fused) fh_fused_vec_geometry(N, ld, &fv_blk, &fv_seg, &fv_per);
+    if (fused) fh_fused_vec_geometry(N, ld, prec, &fv_blk, &fv_seg, &fv_per);
     const int nblk_max = std::max(std::max(nblk_op, nblk_vec), fv_blk * fv_seg);
     if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
     cplx* part1 = (cplx*)p;

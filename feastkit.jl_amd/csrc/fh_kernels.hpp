@@ -83,7 +83,7 @@ struct fh_fused_fin_args {
 };
 void fh_launch_fused_fin(const fh_fused_fin_args& a, int ld, int nodes, hipStream_t st);
 // geometry of the fused vector kernel for a panel of N x ld elements: blocks per segment, segments, elements per thread
-void fh_fused_vec_geometry(int N, int ld, int* nblk, int* nseg, int* per_thread);
+void fh_fused_vec_geometry(int N, int ld, int prec, int* nblk, int* nseg, int* per_thread);
 // R -= alpha Q, [ACC += w alpha P | X += alpha P], P = R + beta P, partials r^T r and |r|^2 ([nodes][nblk*nseg][LD])
 void fh_launch_fused_vec(const fh_vec_args& a, int ld, hipStream_t st);
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);

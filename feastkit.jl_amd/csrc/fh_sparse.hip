@@ -1328,14 +1328,15 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_p_sum(fh_vec_args a) {
 #define FH_FV_THREADS 512
 #define FH_FV_EMAX 28
 
-void fh_fused_vec_geometry(int N, int ld, int* nblk, int* nseg, int* per_thread) {
+void fh_fused_vec_geometry(int N, int ld, int prec, int* nblk, int* nseg, int* per_thread) {
     const size_t total = (size_t)N * ld;
+    const size_t emax = prec == 32 ? FH_FV_EMAX / 2 : FH_FV_EMAX;          // elements a thread owns (complex64: see k_fused_vec)
     size_t g = (total + FH_FV_THREADS - 1) / FH_FV_THREADS;
-    if (g > 256) g = 256;                              // one 512-thread workgroup per CU (2 waves/SIMD, 256 VGPRs): 256 partial rows per node
+    if (g > 256) g = 256;                              // one 512-thread workgroup per CU (2 waves/SIMD, 256 VGPRs): 256 partial rows per node and segment
     if (g < 1) g = 1;
     size_t e = (total + g * FH_FV_THREADS - 1) / (g * FH_FV_THREADS);
     size_t segs = 1;
-    if (e > FH_FV_EMAX) { segs = (e + FH_FV_EMAX - 1) / FH_FV_EMAX; e = (total + g * FH_FV_THREADS * segs - 1) / (g * FH_FV_THREADS * segs); }
+    if (e > emax) { segs = (e + emax - 1) / emax; e = (total + g * FH_FV_THREADS * segs - 1) / (g * FH_FV_THREADS * segs); }
     *nblk = (int)g; *nseg = (int)segs; *per_thread = (int)e;
 }
 
@@ -1477,9 +1478,12 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
     const size_t e0 = (size_t)blockIdx.y * stride * per_thread + (size_t)blockIdx.x * FH_FV_THREADS + t;
     const int prow = blockIdx.y * gridDim.x + blockIdx.x, nprow = gridDim.x * gridDim.y;
     constexpr int GRP = sizeof(CT) == 8 ? 2 : 4;               // elements per thread in flight at once, 3 loads each (complex64 panels with 4: the compiler spills 90 VGPRs)
-    cplx acc[FH_FV_EMAX];
+    // complex64 panels: half as many elements per thread (and twice the segments) -- with 28 the compiler hoists 3 x 28 64-bit
+    // address pairs out of the node loop beside the 112 accumulator registers and spills 74 VGPRs (300 B of scratch per lane)
+    constexpr int EMAX = sizeof(CT) == 8 ? FH_FV_EMAX / 2 : FH_FV_EMAX;
+    cplx acc[EMAX];
 #pragma unroll
-    for (int j = 0; j < FH_FV_EMAX; ++j) acc[j] = cmake(0, 0);
+    for (int j = 0; j < EMAX; ++j) acc[j] = cmake(0, 0);
     bool any = false;
     for (int n = 0; n < a.nodes; ++n) {
         if (!a.s.node_accum[n]) continue;                       // uniform over the grid: nobody writes a partial row
@@ -1505,7 +1509,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
             CT* __restrict__ P = (CT*)a.P + (size_t)n * a.node_stride;
             CT* __restrict__ X = SUM ? nullptr : (CT*)a.X + (size_t)n * a.node_stride;
 #pragma unroll
-            for (int j0 = 0; j0 < FH_FV_EMAX; j0 += GRP) {
+            for (int j0 = 0; j0 < EMAX; j0 += GRP) {
                 if (j0 >= per_thread) continue;                      // (no break: the loop must unroll fully -- acc[] lives in registers)
                 CT pv[GRP], qv[GRP], rv[GRP], xv[GRP];
                 bool ok[GRP];
@@ -1558,7 +1562,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
     if (SUM && any && a.counters && blockIdx.x == 0 && blockIdx.y == 0 && t < LD) atomicAdd(a.counters + 4, 1ull);   // accumulator columns touched
     if (SUM && any) {
 #pragma unroll
-        for (int j = 0; j < FH_FV_EMAX; ++j) {
+        for (int j = 0; j < EMAX; ++j) {
             const size_t e = e0 + (size_t)j * stride;
             if (j < per_thread && e < total) a.sum_acc[e] = cadd(a.sum_acc[e], acc[j]);
         }
@@ -1673,7 +1677,7 @@ static void launch_fused_vec_t(const fh_vec_args& a, dim3 grid, int per_thread, 
 }
 void fh_launch_fused_vec(const fh_vec_args& a, int ld, hipStream_t st) {
     int nblk, nseg, per;
-    fh_fused_vec_geometry(a.N, ld, &nblk, &nseg, &per);
+    fh_fused_vec_geometry(a.N, ld, a.prec, &nblk, &nseg, &per);
     const dim3 grid(nblk, nseg);
     if (a.prec == 32) {
         if (ld == 16) launch_fused_vec_t<cplxf, 16>(a, grid, per, st);
