@@ -477,7 +477,14 @@ struct fh_op_call {
     int m = FH_MAX_LD;     // active columns (measurement only)
     int uniform_coef = 0;  // coefA/coefB identical across columns
     int prec = 64;         // panel precision of X/Y/Bvec/U
+    const cplx* colscale = nullptr;   // row kernel only (fh_spmm_args::colscale): X is a shared panel times per-node column factors
 };
+
+// full-width panels over a real matrix go through the row-per-wave kernel (FH_SPMM_ROW=0: the 4-rows-per-wave gather kernel)
+static bool fh_row_kernel_ok(feasthip_ctx* h, int ld) {
+    static const bool row_off = getenv("FH_SPMM_ROW") && atoi(getenv("FH_SPMM_ROW")) == 0;
+    return h->kind == 2 && ld == 64 && !h->csr.is_complex && h->csr.rp8 && !row_off;
+}
 
 // returns number of blocks used in x (needed to size / read partials)
 static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
@@ -497,8 +504,9 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.nblk_rows = h->csr.nblk; a.blk_start = h->csr.blk_start; a.ext_ptr = h->csr.ext_ptr; a.ext_idx = h->csr.ext_idx;
         a.lcol = lds_kernel ? h->csr.lcol : nullptr;
         // full-width panels over a real matrix: the row-per-wave kernel (FH_SPMM_ROW=0: the 4-rows-per-wave gather kernel)
-        static const bool row_off = getenv("FH_SPMM_ROW") && atoi(getenv("FH_SPMM_ROW")) == 0;
-        a.use_row_kernel = (ld == 64 && !h->csr.is_complex && h->csr.rp8 && !lds_kernel && !row_off) ? 1 : 0;
+        a.use_row_kernel = (fh_row_kernel_ok(h, ld) && !lds_kernel) ? 1 : 0;
+        a.colscale = a.use_row_kernel ? c.colscale : nullptr;
+        if (c.colscale && !a.use_row_kernel) { h->last_error = "internal: column-scaled operand needs the row kernel"; return -1; }
         a.rp8 = h->csr.rp8; a.col8 = h->csr.col8; a.a8 = h->csr.a8; a.b8 = h->csr.b8;
         fh_prof_begin(h, "spmm");
         fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, fh_spmm_grid(a.N, ld), h->stream);
@@ -631,7 +639,7 @@ struct fh_solve_result {
 static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int nodes, const std::vector<cplx>& z,
                      const cplx* RHS, cplx* X, size_t stride, fh_solve_result& res, cplx* sum_acc = nullptr,
                      const std::vector<cplx>* wnode = nullptr, const cplx* shared_src = nullptr,
-                     const double* shared_lambda = nullptr, const cplx* dznode = nullptr) {
+                     const double* shared_lambda = nullptr, const cplx* dznode = nullptr, const double* shared_lambda_host = nullptr) {
     if (h->kind != 2) prec = 64;          // the dense operator kernel takes complex128 panels only
     if (method != 1 || !wnode) sum_acc = nullptr;
     const int N = (int)fh_N(h);
@@ -672,8 +680,10 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     const int nblk_op = fh_op_nblk(h, ld);
     const int nblk_vec = fh_kry_nblk(N, ld, nodes);
     int fv_blk = 0, fv_seg = 0, fv_per = 0;
-    if (fused) fh_fused_vec_geometry(N, ld, prec, &fv_blk, &fv_seg, &fv_per);
-    const int nblk_max = std::max(std::max(nblk_op, nblk_vec), fv_blk * fv_seg);
+    int fv1_blk = 0, fv1_seg = 0, fv1_per = 0;        // geometry of the lazy start's first vector launch
+    if (fused) fh_fused_vec_geometry(N, ld, prec == 32, &fv_blk, &fv_seg, &fv_per);
+    if (fused) fh_fused_vec_geometry(N, ld, 1, &fv1_blk, &fv1_seg, &fv1_per);
+    const int nblk_max = std::max(std::max(std::max(nblk_op, nblk_vec), fv_blk * fv_seg), fv1_blk * fv1_seg);
     if ((rc = fh_get_buf(h, "kry_partials", 2 * (size_t)nodes * nblk_max * ld * sizeof(cplx), &p))) return rc;
     cplx* part1 = (cplx*)p;
     cplx* part2 = part1 + (size_t)nodes * nblk_max * ld;
@@ -759,7 +769,25 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     }
     va.X = Xk;
     const int vprec = prec;
-    if (shared_start) {
+    // Lazy start (fused iteration, row kernel): residual and direction of every node are the ONE source panel times a
+    // per-node column factor, so neither is written here; the first operator product reads the source itself and the first
+    // vector kernel writes R and P (fh_sparse.hip: k_cocg_init_lazy).  FH_NO_LAZY_START=1: materialise them as before.
+    static const bool lazy_off = getenv("FH_NO_LAZY_START") != nullptr;
+    const bool lazy = shared_start && fused && fh_row_kernel_ok(h, ld) && !lazy_off && (!shared_lambda || shared_lambda_host) &&
+                      !(getenv("FH_LDS_SPMM") && atoi(getenv("FH_LDS_SPMM")) != 0);
+    cplx* dfs = nullptr;
+    if (lazy) {
+        std::vector<cplx> fs(nl, cmake(1, 0));
+        if (shared_lambda_host)
+            for (int e = 0; e < nodes; ++e)
+                for (int c = 0; c < m; ++c) fs[(size_t)e * ld + c] = cdiv(cmake(1, 0), cmake(z[e].x - shared_lambda_host[c], z[e].y));
+        if ((rc = fh_upload_coefs(h, "kry_fscale", fs, &dfs))) return rc;
+        fh_vec_args vs = va;
+        vs.Q = shared_src; vs.first_scale = dfs;
+        fh_launch_cocg_init_lazy(vs, ld, nblk_vec, nodes, h->stream);
+        fa.nblk = nblk_vec;
+        fh_launch_fin_init(fa, ld, nodes, h->stream);
+    } else if (shared_start) {
         fh_vec_args vs = va;
         vs.Q = shared_src; vs.lambda = shared_lambda; vs.znode = dznode;
         fh_launch_cocg_init_shared(vs, ld, nblk_vec, nodes, h->stream);
@@ -819,14 +847,17 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
                 res.op_calls += 2;
             } else if (fused) {
                 // Q = S P (stored in V), sigma = p^T q, kappa = q^T q (fh_sparse.hip, fused COCG)
-                oc.X = P; oc.Y = V; oc.U = nullptr; oc.dot_mode = 6; oc.node_active = s.node_active;
+                const bool first_lazy = lazy && it + k == 0;
+                oc.X = first_lazy ? (const void*)shared_src : P; oc.x_stride = first_lazy ? 0 : panel; oc.colscale = first_lazy ? dfs : nullptr;
+                oc.Y = V; oc.U = nullptr; oc.dot_mode = 6; oc.node_active = s.node_active;
                 oc.partial1 = sp[0]; oc.partial2 = sp[1];
+                va.first_src = first_lazy ? shared_src : nullptr; va.first_scale = first_lazy ? dfs : nullptr;
                 fh_fused_fin_args ff;
                 ff.s = s; ff.sig = sp[0]; ff.kap = sp[1];
                 ff.rho = part1; ff.rr = part2; ff.tickets = d_tickets; ff.final_check = 0;
                 ff.predict_stop = (h->rtol >= 1e-3 && h->atol == 0.0) ? 1 : 0;
                 ff.nblk_op = fh_apply_operator(h, ld, oc);
-                ff.nblk_vec = (it + k == 0) ? fa.nblk : fv_blk * fv_seg;      // first iteration: the init kernel's partial rows
+                ff.nblk_vec = (it + k == 0) ? fa.nblk : ((lazy && it + k == 1) ? fv1_blk * fv1_seg : fv_blk * fv_seg);      // first iteration: the init kernel's partial rows; second (lazy start): the half-geometry launch's
                 fh_prof_begin(h, "dot_finalize"); fh_launch_fused_fin(ff, ld, nodes, h->stream); fh_prof_end(h);
                 fh_prof_begin(h, "cocg_vec"); fh_launch_fused_vec(va, ld, h->stream); fh_prof_end(h);
                 res.op_calls += 1;
@@ -878,7 +909,7 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
         // the stop test of the last step: true norms from the last vector kernel's partials (no SpMM follows it)
         fh_fused_fin_args ff;
         ff.s = s; ff.sig = ff.kap = nullptr; ff.rho = part1; ff.rr = part2; ff.tickets = d_tickets;
-        ff.nblk_op = 0; ff.nblk_vec = fv_blk * fv_seg; ff.final_check = 1; ff.predict_stop = 0;
+        ff.nblk_op = 0; ff.nblk_vec = (lazy && it == 1) ? fv1_blk * fv1_seg : fv_blk * fv_seg; ff.final_check = 1; ff.predict_stop = 0;
         fh_launch_fused_fin(ff, ld, nodes, h->stream);
     }
     FH_CHECK(hipStreamSynchronize(h->stream));
@@ -1306,7 +1337,7 @@ static int fh_contour_apply_panel(feasthip_ctx* h, int64_t m64, const cplx* dQ, 
             fh_launch_init_guess(va, ld, fh_vec_nblk(N, ld), nodes, h->stream);
         }
         rc = fh_krylov(h, h->solver == FEASTHIP_SOLVER_COCG ? 1 : 0, h->factor_precision, ld, m, nodes, z, Rhs, Y, panel, sr,
-                       sum_acc, &w, shared_src, dlam, dz);
+                       sum_acc, &w, shared_src, dlam, dz, ritz_lambda);
         if (rc) return rc;
         status = sr.status;
         h->last_node_iters = sr.node_iters;

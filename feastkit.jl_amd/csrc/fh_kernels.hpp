@@ -21,6 +21,10 @@ struct fh_spmm_args {
     int prec;                                 // 64 | 32
     const int* rp8 = nullptr; const int* col8 = nullptr; const double* a8 = nullptr; const double* b8 = nullptr;   // chunk-of-8 rows (fh_csr)
     int use_row_kernel = 0;                   // LD = 64 and real matrix values: k_spmm_row (one wave per row); partial rows = fh_spmm_row_grid(N)
+    // k_spmm_row only: X holds a panel SHARED by the nodes whose column c is to be read as colscale[node][c] * X (the lazy
+    // start of the sum-mode COCG sweeps: every node's first direction is one source panel times a per-column factor).  The
+    // kernel forms y = colscale * (S x) and takes its dots with colscale * x.  Null: X as is.
+    const cplx* colscale = nullptr;
     // row blocks of a renumbered matrix (fh_common.hpp: fh_csr); lcol == null: not renumbered, k_spmm serves
     int nblk_rows; const int* blk_start; const int* ext_ptr; const int* ext_idx; const unsigned short* lcol;
 };
@@ -44,6 +48,10 @@ struct fh_vec_args {
     unsigned long long* counters;   // measurement: [2] += active columns of this launch (update kernels), may be null
     // sum mode (COCG inside contour_apply): the per-node solutions are never formed; every step
     // alpha p of every node goes straight into the shared accumulator  ACC += w_node alpha [scale] p
+    // lazy start (first fused iteration only): residual and direction of every node are first_scale[node][c] * first_src,
+    // the panels R and P do not exist yet -- the kernel reads first_src in their place and WRITES them
+    const cplx* first_src;     // N x LD fp64 shared source panel, or null
+    const cplx* first_scale;   // [nodes x LD]
     cplx* sum_acc;             // N x LD fp64 accumulator, or null (solutions are updated in X)
     const cplx* wnode;         // [nodes] quadrature weights
     const double* sum_scale;   // [nodes x LD] column scale of the correction (mixed precision) or null
@@ -66,6 +74,9 @@ void fh_launch_xr_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipS
 void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 // sum-mode start from one shared source panel (a.Q = source, a.lambda/a.znode = warm-start factors or null)
 void fh_launch_cocg_init_shared(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
+// the same start without materialising R and P: only the per-node dot partials (a.Q = source, a.first_scale = per-node column
+// factors); the first fused iteration then runs with fh_spmm_args::colscale / fh_vec_args::first_src
+void fh_launch_cocg_init_lazy(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
 // OUT = [Re](SRC * rho_c + ACC)
 void fh_launch_sum_finish(const cplx* src, const cplx* rho, const cplx* acc, cplx* out, int N, int ld, int real_part, hipStream_t st);
 void fh_launch_cocg_update(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st);
@@ -83,7 +94,7 @@ struct fh_fused_fin_args {
 };
 void fh_launch_fused_fin(const fh_fused_fin_args& a, int ld, int nodes, hipStream_t st);
 // geometry of the fused vector kernel for a panel of N x ld elements: blocks per segment, segments, elements per thread
-void fh_fused_vec_geometry(int N, int ld, int prec, int* nblk, int* nseg, int* per_thread);
+void fh_fused_vec_geometry(int N, int ld, int half, int* nblk, int* nseg, int* per_thread);
 // R -= alpha Q, [ACC += w alpha P | X += alpha P], P = R + beta P, partials r^T r and |r|^2 ([nodes][nblk*nseg][LD])
 void fh_launch_fused_vec(const fh_vec_args& a, int ld, hipStream_t st);
 void fh_launch_fin_init(const fh_fin_args& a, int ld, int nodes, hipStream_t st);

@@ -385,6 +385,8 @@ __global__ __launch_bounds__(FH_ROW_THREADS, FH_ROW_WAVES) void k_spmm_row(fh_sp
         cplx ca = a.coefA[node * LD + lane];
         cplx cb = a.coefB[node * LD + lane];
         if (UNIF) { ca = cmake(fh_uniform(ca.x), fh_uniform(ca.y)); cb = cmake(fh_uniform(cb.x), fh_uniform(cb.y)); }
+        const bool scaled = a.colscale != nullptr;              // lazy start: the panel is colscale[node][column] * X
+        const cplx fs = scaled ? a.colscale[node * LD + lane] : cmake(1, 0);
         double d1x = 0.0, d1y = 0.0, d2x = 0.0, d2y = 0.0;
         for (int i = row_lo + slot * WPB + wave; i < row_hi; i += band) {
             const int c0 = rp8[i], c1 = rp8[i + 1];
@@ -422,6 +424,8 @@ __global__ __launch_bounds__(FH_ROW_THREADS, FH_ROW_WAVES) void k_spmm_row(fh_sp
             cplx u = cmake(ux, uy), v = cmake(vx, vy);
             if (BIDENT) v = to_d(xown);
             cplx accd = cadd(cmul(cb, v), cmul(ca, u));
+            cplx xo = to_d(xown);
+            if (scaled) { accd = cmul(fs, accd); xo = cmul(fs, xo); }       // S (x diag(f)) = (S x) diag(f)
             if (Bv) accd = csub(to_d(fh_ld_nt((Bv + (size_t)i * LD) + lane)), accd);
             const CT acc = cvt<CT>(accd);
             fh_st_nt((Y + (size_t)i * LD) + lane, acc);
@@ -430,15 +434,15 @@ __global__ __launch_bounds__(FH_ROW_THREADS, FH_ROW_WAVES) void k_spmm_row(fh_sp
                 const cplx t1 = cmulc(to_d(fh_ld_nt((U + (size_t)i * LD) + lane)), accd);
                 d1x += t1.x; d1y += t1.y;
             } else if (a.dot_mode == 2) {
-                const cplx t1 = cmulc(accd, to_d(xown));
+                const cplx t1 = cmulc(accd, xo);
                 d1x += t1.x; d1y += t1.y; d2x += cabs2(accd);
             } else if (a.dot_mode == 3) {
                 d2x += cabs2(accd);
             } else if (a.dot_mode == 4) {
-                const cplx t1 = cmul(to_d(xown), accd);
+                const cplx t1 = cmul(xo, accd);
                 d1x += t1.x; d1y += t1.y;
             } else if (a.dot_mode == 6) {
-                const cplx t1 = cmul(to_d(xown), accd), t2 = cmul(accd, accd);
+                const cplx t1 = cmul(xo, accd), t2 = cmul(accd, accd);
                 d1x += t1.x; d1y += t1.y; d2x += t2.x; d2y += t2.y;
             }
         }
@@ -1181,6 +1185,35 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_init_shared(fh_vec_args a) {
     fh_block_reduce_cols<LD>(d2, red, a.partial2 + o);
 }
 
+// The same start WITHOUT the panels: r^T r and |r|^2 of R_node = f_node,c * SRC are f^2 sum SRC^2 and |f|^2 sum |SRC|^2 -- one
+// pass over the ONE source panel gives the partial rows of every node; R and P are first written by the first fused vector
+// kernel (fh_vec_args::first_src), the first operator product reads SRC itself (fh_spmm_args::colscale).  Saves, per sweep,
+// 2 x nodes panel writes here, (nodes - 1) panel reads in the first product and 2 x nodes panel reads in the first update.
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_cocg_init_lazy(fh_vec_args a) {
+    const size_t total = (size_t)a.N * LD;
+    const int c = threadIdx.x % LD;
+    cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const cplx v = a.Q[e];
+        d1 = cadd(d1, cmul(v, v));
+        d2.x += cabs2(v);
+    }
+    __shared__ cplx red[FH_BLOCK];
+    __shared__ cplx tot[2][LD];
+    fh_block_reduce_cols<LD>(d1, red, &tot[0][0]);
+    fh_block_reduce_cols<LD>(d2, red, &tot[1][0]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < a.nodes * LD; idx += FH_BLOCK) {
+        const int n = idx / LD, cc = idx % LD;
+        const cplx f = a.first_scale[n * LD + cc];
+        const size_t o = ((size_t)n * gridDim.x + blockIdx.x) * LD + cc;
+        a.partial1[o] = cmul(cmul(f, f), tot[0][cc]);
+        a.partial2[o] = cmake(cabs2(f) * tot[1][cc].x, 0.0);
+    }
+    (void)c;
+}
+
 // Q_proj of a sum-mode sweep: OUT = [Re] ( SRC * rho_c + ACC ), rho_c = sum_e w_e / (z_e - lambda_c) -- the weighted sum of
 // the warm starts in closed form (no per-node panels) plus the accumulated Krylov corrections.  rho == null: OUT = [Re] ACC.
 template <int LD>
@@ -1328,9 +1361,10 @@ __global__ __launch_bounds__(FH_BLOCK) void k_cocg_p_sum(fh_vec_args a) {
 #define FH_FV_THREADS 512
 #define FH_FV_EMAX 28
 
-void fh_fused_vec_geometry(int N, int ld, int prec, int* nblk, int* nseg, int* per_thread) {
+// half != 0: the geometry of the launches that own FH_FV_EMAX / 2 elements per thread (complex64 panels; the lazy start's first launch)
+void fh_fused_vec_geometry(int N, int ld, int half, int* nblk, int* nseg, int* per_thread) {
     const size_t total = (size_t)N * ld;
-    const size_t emax = prec == 32 ? FH_FV_EMAX / 2 : FH_FV_EMAX;          // elements a thread owns (complex64: see k_fused_vec)
+    const size_t emax = half ? FH_FV_EMAX / 2 : FH_FV_EMAX;          // elements a thread owns (see k_fused_vec)
     size_t g = (total + FH_FV_THREADS - 1) / FH_FV_THREADS;
     if (g > 256) g = 256;                              // one 512-thread workgroup per CU (2 waves/SIMD, 256 VGPRs): 256 partial rows per node and segment
     if (g < 1) g = 1;
@@ -1463,7 +1497,9 @@ __global__ __launch_bounds__(FH_FIN_BLOCK) void k_fused_fin(fh_fused_fin_args a)
     }
 }
 
-template <typename CT, int LD, bool SUM>
+// FIRST: the lazy start's first iteration -- residual and direction of node n are first_scale[n][c] * first_src (shared by
+// the nodes: the reads of the 51 MB source panel are served by the caches after the first node), R and P are written here
+template <typename CT, int LD, bool SUM, bool FIRST>
 __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, int per_thread) {
     // grid (nblk, nseg).  A thread OWNS per_thread (<= 28) elements of the panel, G * 512 apart (a multiple of LD: one
     // column per thread), for every node: the weighted steps of all nodes are summed in registers and the shared
@@ -1480,7 +1516,9 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
     constexpr int GRP = sizeof(CT) == 8 ? 2 : 4;               // elements per thread in flight at once, 3 loads each (complex64 panels with 4: the compiler spills 90 VGPRs)
     // complex64 panels: half as many elements per thread (and twice the segments) -- with 28 the compiler hoists 3 x 28 64-bit
     // address pairs out of the node loop beside the 112 accumulator registers and spills 74 VGPRs (300 B of scratch per lane)
-    constexpr int EMAX = sizeof(CT) == 8 ? FH_FV_EMAX / 2 : FH_FV_EMAX;
+    // (the lazy start's first launch likewise: its source-panel loads are one more operand per element -- 152 VGPRs spilled
+    //  at 28 elements per thread)
+    constexpr int EMAX = (sizeof(CT) == 8 || FIRST) ? FH_FV_EMAX / 2 : FH_FV_EMAX;
     cplx acc[EMAX];
 #pragma unroll
     for (int j = 0; j < EMAX; ++j) acc[j] = cmake(0, 0);
@@ -1504,6 +1542,8 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
                 coef = cmul(a.wnode[n], a.s.alpha[i]);
                 if (a.sum_scale) { const double sc = a.sum_scale[i]; coef.x *= sc; coef.y *= sc; }
             }
+            const cplx fsc = FIRST ? a.first_scale[i] : cmake(1, 0);
+            const cplx* __restrict__ fsrc = a.first_src;
             const CT* __restrict__ Q = (const CT*)a.V + (size_t)n * a.node_stride;
             CT* __restrict__ R = (CT*)a.R + (size_t)n * a.node_stride;
             CT* __restrict__ P = (CT*)a.P + (size_t)n * a.node_stride;
@@ -1519,8 +1559,9 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
                     ok[u] = (j0 + u < per_thread) && e < total;
                     pv[u] = fh_czero<CT>(); qv[u] = fh_czero<CT>(); rv[u] = fh_czero<CT>(); xv[u] = fh_czero<CT>();
                     if (ok[u]) {
-                        pv[u] = P[e];
-                        if (act) { qv[u] = fh_ld_nt(Q + e); rv[u] = R[e]; }
+                        if (FIRST) { pv[u] = cvt<CT>(cmul(fsc, fsrc[e])); rv[u] = pv[u]; }
+                        else pv[u] = P[e];
+                        if (act) { qv[u] = fh_ld_nt(Q + e); if (!FIRST) rv[u] = R[e]; }
                         if (!SUM) xv[u] = X[e];
                     }
                 }
@@ -1613,6 +1654,12 @@ void fh_launch_cocg_init(const fh_vec_args& a, int ld, int nblk, int nodes, hipS
 void fh_launch_cocg_init_shared(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
     FH_DISPATCH_VEC(a.prec, ld, k_cocg_init_shared, dim3(nblk, nodes), st, a);
 }
+void fh_launch_cocg_init_lazy(const fh_vec_args& a, int ld, int nblk, int nodes, hipStream_t st) {
+    (void)nodes;
+    if (ld == 16) hipLaunchKernelGGL((k_cocg_init_lazy<16>), dim3(nblk), dim3(FH_BLOCK), 0, st, a);
+    else if (ld == 32) hipLaunchKernelGGL((k_cocg_init_lazy<32>), dim3(nblk), dim3(FH_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_cocg_init_lazy<64>), dim3(nblk), dim3(FH_BLOCK), 0, st, a);
+}
 void fh_launch_sum_finish(const cplx* src, const cplx* rho, const cplx* acc, cplx* out, int N, int ld, int real_part, hipStream_t st) {
     const size_t total = (size_t)N * ld;
     const int nblk = (int)std::min<size_t>((total + FH_BLOCK - 1) / FH_BLOCK, 2048);
@@ -1672,12 +1719,17 @@ void fh_launch_fused_fin(const fh_fused_fin_args& a, int ld, int nodes, hipStrea
 }
 template <typename CT, int LD>
 static void launch_fused_vec_t(const fh_vec_args& a, dim3 grid, int per_thread, hipStream_t st) {
-    if (a.sum_acc) hipLaunchKernelGGL((k_fused_vec<CT, LD, true>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
-    else hipLaunchKernelGGL((k_fused_vec<CT, LD, false>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
+    if (a.first_src) {       // lazy start: sum mode, fp64 panels only (fh_krylov)
+        if (a.sum_acc) hipLaunchKernelGGL((k_fused_vec<CT, LD, true, true>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
+        else hipLaunchKernelGGL((k_fused_vec<CT, LD, false, true>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
+        return;
+    }
+    if (a.sum_acc) hipLaunchKernelGGL((k_fused_vec<CT, LD, true, false>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
+    else hipLaunchKernelGGL((k_fused_vec<CT, LD, false, false>), grid, dim3(FH_FV_THREADS), 0, st, a, per_thread);
 }
 void fh_launch_fused_vec(const fh_vec_args& a, int ld, hipStream_t st) {
     int nblk, nseg, per;
-    fh_fused_vec_geometry(a.N, ld, a.prec, &nblk, &nseg, &per);
+    fh_fused_vec_geometry(a.N, ld, a.prec == 32 || a.first_src != nullptr, &nblk, &nseg, &per);
     const dim3 grid(nblk, nseg);
     if (a.prec == 32) {
         if (ld == 16) launch_fused_vec_t<cplxf, 16>(a, grid, per, st);
