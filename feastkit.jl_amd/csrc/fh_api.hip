@@ -505,8 +505,8 @@ static int fh_apply_operator(feasthip_ctx* h, int ld, const fh_op_call& c) {
         a.lcol = lds_kernel ? h->csr.lcol : nullptr;
         // full-width panels over a real matrix: the row-per-wave kernel (FH_SPMM_ROW=0: the 4-rows-per-wave gather kernel)
         a.use_row_kernel = (fh_row_kernel_ok(h, ld) && !lds_kernel) ? 1 : 0;
-        a.colscale = a.use_row_kernel ? c.colscale : nullptr;
-        if (c.colscale && !a.use_row_kernel) { h->last_error = "internal: column-scaled operand needs the row kernel"; return -1; }
+        a.colscale = c.colscale;
+        if (c.colscale && (lds_kernel || c.prec != 64 || h->csr.is_complex)) { h->last_error = "internal: column-scaled operand needs a gather kernel over a real matrix on complex128 panels"; return -1; }
         a.rp8 = h->csr.rp8; a.col8 = h->csr.col8; a.a8 = h->csr.a8; a.b8 = h->csr.b8;
         fh_prof_begin(h, "spmm");
         fh_launch_spmm(a, ld, h->csr.is_complex != 0, h->csr.b_identity != 0, fh_spmm_grid(a.N, ld), h->stream);
@@ -769,11 +769,11 @@ static int fh_krylov(feasthip_ctx* h, int method, int prec, int ld, int m, int n
     }
     va.X = Xk;
     const int vprec = prec;
-    // Lazy start (fused iteration, row kernel): residual and direction of every node are the ONE source panel times a
+    // Lazy start (fused iteration over a CSR operator, both gather kernels): residual and direction of every node are the ONE source panel times a
     // per-node column factor, so neither is written here; the first operator product reads the source itself and the first
     // vector kernel writes R and P (fh_sparse.hip: k_cocg_init_lazy).  FH_NO_LAZY_START=1: materialise them as before.
-    static const bool lazy_off = getenv("FH_NO_LAZY_START") != nullptr;
-    const bool lazy = shared_start && fused && fh_row_kernel_ok(h, ld) && !lazy_off && (!shared_lambda || shared_lambda_host) &&
+    const bool lazy_off = getenv("FH_NO_LAZY_START") != nullptr;    // read per call (the tests flip it)
+    const bool lazy = shared_start && fused && h->kind == 2 && !h->csr.is_complex && !lazy_off && (!shared_lambda || shared_lambda_host) &&
                       !(getenv("FH_LDS_SPMM") && atoi(getenv("FH_LDS_SPMM")) != 0);
     cplx* dfs = nullptr;
     if (lazy) {

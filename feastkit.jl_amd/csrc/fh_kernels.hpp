@@ -21,7 +21,7 @@ struct fh_spmm_args {
     int prec;                                 // 64 | 32
     const int* rp8 = nullptr; const int* col8 = nullptr; const double* a8 = nullptr; const double* b8 = nullptr;   // chunk-of-8 rows (fh_csr)
     int use_row_kernel = 0;                   // LD = 64 and real matrix values: k_spmm_row (one wave per row); partial rows = fh_spmm_row_grid(N)
-    // k_spmm_row only: X holds a panel SHARED by the nodes whose column c is to be read as colscale[node][c] * X (the lazy
+    // k_spmm_row / k_spmm (complex128 panels): X holds a panel SHARED by the nodes whose column c is to be read as colscale[node][c] * X (the lazy
     // start of the sum-mode COCG sweeps: every node's first direction is one source panel times a per-column factor).  The
     // kernel forms y = colscale * (S x) and takes its dots with colscale * x.  Null: X as is.
     const cplx* colscale = nullptr;

@@ -118,7 +118,9 @@ template <typename CT> __device__ __forceinline__ CT fh_czero();
 template <> __device__ __forceinline__ cplx fh_czero<cplx>() { return cmake(0, 0); }
 template <> __device__ __forceinline__ cplxf fh_czero<cplxf>() { return cmakef(0.f, 0.f); }
 
-template <typename CT, typename VT, int LD, bool BIDENT>
+// SCALED: the lazy start's first product (fh_spmm_args::colscale); its own instantiation -- the two extra registers of the
+// column factor spill 6-14 VGPRs at this kernel's 128-VGPR budget
+template <typename CT, typename VT, int LD, bool BIDENT, bool SCALED = false>
 __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
     constexpr int NT = LD / 16;          // column tiles
     constexpr int SLICES = 8 / NT;       // row slices
@@ -164,6 +166,8 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
         const CT* __restrict__ U = a.U ? (const CT*)a.U + (size_t)node * a.u_node_stride : nullptr;
         const CT ca = cvt<CT>(a.coefA[node * LD + c]);
         const CT cb = cvt<CT>(a.coefB[node * LD + c]);
+        constexpr bool scaled = SCALED;                       // lazy start: the panel is colscale[node][column] * X (see k_spmm_row)
+        const CT fsc = scaled ? cvt<CT>(a.colscale[node * LD + c]) : fh_czero<CT>();
         cplx d1 = cmake(0, 0), d2 = cmake(0, 0);
         // software pipeline over this group's rows: row pointers are fetched two rows ahead and
         // the first 16 nonzeros' (column, A, B) one row ahead, so a row's critical path is the
@@ -256,20 +260,22 @@ __global__ __launch_bounds__(FH_BLOCK, 4) void k_spmm(fh_spmm_args a) {
                 }
             }
             if (k1 == k0 && i + band < row_hi) xfar = X[(size_t)fh_bc16(ncol, 0) * LD + c];   // empty row: nothing issued above
+            CT xo = xown;
+            if (scaled) { acc = cmul(fsc, acc); xo = cmul(fsc, xown); }       // S (x diag(f)) = (S x) diag(f)
             if (Bv) acc = csub(fh_ld_nt(Bv + (size_t)i * LD + c), acc);
             fh_st_nt(Y + (size_t)i * LD + c, acc);
             const cplx accd = to_d(acc);
             if (a.dot_mode == 1) {
                 d1 = cadd(d1, cmulc(to_d(fh_ld_nt(U + (size_t)i * LD + c)), accd));
             } else if (a.dot_mode == 2) {
-                d1 = cadd(d1, cmulc(accd, to_d(xown)));
+                d1 = cadd(d1, cmulc(accd, to_d(xo)));
                 d2.x += cabs2(accd);
             } else if (a.dot_mode == 3) {
                 d2.x += cabs2(accd);
             } else if (a.dot_mode == 4) {
-                d1 = cadd(d1, cmul(to_d(xown), accd));   // unconjugated p^T (S p), COCG
+                d1 = cadd(d1, cmul(to_d(xo), accd));   // unconjugated p^T (S p), COCG
             } else if (a.dot_mode == 6) {
-                d1 = cadd(d1, cmul(to_d(xown), accd));   // p^T q
+                d1 = cadd(d1, cmul(to_d(xo), accd));   // p^T q
                 d2 = cadd(d2, cmul(accd, accd));         // q^T q (unconjugated)
             }
         }
@@ -722,6 +728,13 @@ static void launch_spmm_lds(const fh_spmm_args& a, bool bident, hipStream_t st) 
 template <typename CT, typename VT, int LD>
 static void launch_spmm_ld(const fh_spmm_args& a, bool bident, int nblk, hipStream_t st) {
     dim3 grid(nblk), block(FH_BLOCK);
+    if constexpr (sizeof(CT) == sizeof(cplx) && sizeof(VT) == sizeof(double)) {
+        if (a.colscale) {                  // lazy start: COCG, so real matrices, and complex128 panels only
+            if (bident) hipLaunchKernelGGL((k_spmm<CT, VT, LD, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_spmm<CT, VT, LD, false, true>), grid, block, 0, st, a);
+            return;
+        }
+    }
     if (bident)
         hipLaunchKernelGGL((k_spmm<CT, VT, LD, true>), grid, block, 0, st, a);
     else

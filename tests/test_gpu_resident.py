@@ -186,3 +186,37 @@ def test_drivers_resident_loop_equals_per_primitive_loop(engine, case):
         Bx = r.q if Bd is None else Bd @ r.q
         hres = np.linalg.norm(Ax - Bx * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0)
         assert hres.max() <= 1e-10
+
+
+@pytest.mark.parametrize("N,m,kind", [(900, 12, "real"), (1100, 24, "real"), (700, 40, "real_bid"), (1500, 64, "real"), (2100, 64, "real_bid")])
+def test_lazy_start_matches_materialised_start(engine, monkeypatch, N, m, kind):
+    """The COCG sweep that never writes its start residual / direction (first product reads the shared source panel times
+    per-node column factors: both gather kernels, every panel width) against the same sweep with the start materialised (FH_NO_LAZY_START) and against sparse LU."""
+    import scipy.sparse.linalg  # noqa: F401
+    A, B = sparse_pair(N, 21 + m, cplx=False, b_identity=(kind == "real_bid"))
+    engine.set_problem(A, B)
+    Z, W = contour8(engine)
+    real_part = True
+    engine.set_real_projection(real_part)
+    engine.set_node_range(0, len(Z))
+    engine.set_solver("cocg", rtol=1e-12, atol=0.0, maxit=3000)
+    Q = rand_block(N, m, 8, cplx=not real_part)
+    dQ = engine.upload(Q)
+    lam = np.linspace(2.2, 8.8, m) if real_part else None          # warm start x0 = q / (z - lambda) per column
+    out = {}
+    for mode in ("lazy", "materialised"):
+        if mode == "materialised":
+            monkeypatch.setenv("FH_NO_LAZY_START", "1")
+        dP, st, stats = engine.contour_apply(dQ, m, ritz_lambda=lam)
+        assert (st[:len(Z)] == 0).all()
+        status, _ = engine.contour_apply_resident(dQ, m, ritz_lambda=lam)
+        assert (status[:len(Z)] == 0).all()
+        out[mode] = (engine.download(dP), engine.download(engine.export_resident(m, which=1)), stats["krylov_iterations"])
+    monkeypatch.delenv("FH_NO_LAZY_START")
+    want = oracle_sweep(A, B, Q, Z, W, 2.0, real_part)
+    scale = np.abs(want).max()
+    for mode in out:
+        assert np.abs(out[mode][0] - want).max() <= 1e-9 * scale
+        assert np.abs(out[mode][1] - want).max() <= 1e-9 * scale
+    assert np.abs(out["lazy"][0] - out["materialised"][0]).max() <= 1e-9 * scale      # both stop at rtol 1e-12 of their own recurrences
+    assert abs(out["lazy"][2] - out["materialised"][2]) <= max(2, out["lazy"][2] // 50)
