@@ -352,10 +352,13 @@ def main():
             return None
         avg_ms = total_ms / launches
         achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # every instantiation of the kernel the class launches (sum / plain, lazy-start first launch), weighted by launches
+        tb = tl = 0
         for name, rec in pmc.items():
-            if name.replace(" ", "").startswith("void" + kernel.split("<")[0]) and ("cplx," in name or "<cplx" in name) and "cplxf" not in name:
-                traffic = rec["mean_hbm_bytes_per_launch"]
+            if name.replace(" ", "").startswith("void" + kernel.split("<")[0] + "<") and ("cplx," in name or "<cplx" in name) and "cplxf" not in name:
+                tb += rec["mean_hbm_bytes_per_launch"] * rec["launches"]
+                tl += rec["launches"]
+        traffic = int(tb / tl) if tl else None
         return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "peak_measured": HBM_MEASURED_GBS,
                 "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS["copy"], 4), "traffic": traffic,
@@ -382,12 +385,13 @@ def main():
         _, v_launches = eng.profile_get("cocg_vec")
         if v_launches:
             # fused vector kernel, counted on the device per launch: a column that goes on iterating reads p, q, r and writes
-            # r, p (5 passes); a column on its last step only has its p read for the accumulator (1 pass); the shared
+            # r, p (5 passes; 4 in the first launch of a lazy start, which reads q and the shared source); a column on its last step only has its p read for the accumulator (1 pass); the shared
             # accumulator is read and written for the columns that stepped at any node
             _, cont_cols = eng.profile_get("update.continuing_columns")
             _, acc_cols = eng.profile_get("update.accumulator_columns")
+            _, first_cols = eng.profile_get("update.first_launch_columns")      # lazy start's first launch: 4 passes, not 5
             cands.append(roof("cocg_vec", "k_fused_vec<cplx,64,true>",
-                              (cont_cols * 5 + max(upd_cols - cont_cols, 0) * 1 + acc_cols * 2) * N * 16))
+                              (cont_cols * 5 - first_cols + max(upd_cols - cont_cols, 0) * 1 + acc_cols * 2) * N * 16))
         else:                                                     # FH_COCG_FUSED=0: the five-launch iteration
             _, p_launches = eng.profile_get("cocg_p")
             cands.append(roof("cocg_xr", "k_cocg_update<cplx,64>", upd_cols * 3 * N * 16))

@@ -3125,10 +3125,10 @@ extern "C" int feasthip_profile_get(feasthip_handle h, const char* kernel_class,
     // device-side work counters: [0] active node-sweeps of the SpMM, [1] its active column x vector passes, [2] columns that
     // took a step in an update kernel, [3] of those the columns that go on iterating (the fused vector kernel reads and
     // writes five panels for them, one for a column on its last step), [4] distinct columns whose accumulator entries a
-    // sum-mode launch read and wrote
+    // sum-mode launch read and wrote, [5] the part of [3] counted in the first vector launch of a lazy start (four passes)
     static const char* const names[] = {"spmm.node_launches", "spmm.column_passes", "update.active_columns", "update.continuing_columns",
-                                        "update.accumulator_columns"};
-    for (int k = 0; k < 5; ++k)
+                                        "update.accumulator_columns", "update.first_launch_columns"};
+    for (int k = 0; k < 6; ++k)
         if (!strcmp(kernel_class, names[k])) {
             unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             hipStreamSynchronize(h->stream);

@@ -1544,6 +1544,7 @@ __global__ __launch_bounds__(FH_FV_THREADS, 2) void k_fused_vec(fh_vec_args a, i
         if (a.counters && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
             atomicAdd(a.counters + 2, (unsigned long long)a.s.node_accum[n]);          // columns stepping at this node
             atomicAdd(a.counters + 3, (unsigned long long)a.s.node_active[n]);         // ... that go on iterating (5 panel passes each)
+            if (FIRST) atomicAdd(a.counters + 5, (unsigned long long)a.s.node_active[n]);   // ... in a lazy start's first launch (4: q and the source read, r and p written)
         }
         double d1x = 0.0, d1y = 0.0, d2 = 0.0;
         if (step) {
