@@ -37,3 +37,26 @@ def test_host_policy_under_asan_ubsan(tmp_path):
     run = subprocess.run([str(exe), "150", "11"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert run.returncode == 0 and run.stdout.strip().endswith("ok 150"), run.stdout[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_host_multifrontal_plan_under_asan_ubsan(tmp_path):
+    """The symbolic phase of the multifrontal sparse direct solver (csrc/fh_mf.hpp: nested dissection, fronts, padded groups,
+    assembly and extend-add maps) under the same sanitizers: plan invariants on grid, random, disconnected and degenerate
+    patterns, and the plan EXECUTED on the CPU (partial pivoting inside the fully-summed blocks, substitution through the
+    tree) against the residual of the solve (tests/host_mf_harness.cpp); then the plan of cfg 3's pattern: a tenth of the
+    band LU's work and under 0.85 GB of factors per quadrature node."""
+    exe = tmp_path / "host_mf_harness"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-Wall", "-Wextra",
+           os.path.join(ROOT, "tests", "host_mf_harness.cpp"), "-o", str(exe)]
+    build = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert build.returncode == 0, build.stdout[-4000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert run.returncode == 0 and run.stdout.strip().endswith("OK"), run.stdout[-4000:]
+    run = subprocess.run([str(exe), "stats", "50", "40", "25", "64"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout[-4000:]
+    words = run.stdout.split()
+    flops = float(words[words.index("flops") + 1])
+    store = float(words[words.index("store") + 1])
+    assert flops < 1.0e11 and store < 0.85, run.stdout
