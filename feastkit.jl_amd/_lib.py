@@ -74,6 +74,7 @@ SYMBOLS = {
     "feasthip_matmul": (_i, [_vp, _i, _i64, _vp, _vp]),
     "feasthip_matmul_dev": (_i, [_vp, _i, _i64, _vp, _vp]),
     "feasthip_band_plan": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "feasthip_direct_plan_flops": (_i, [_vp, _vp]),
     "feasthip_release_factors": (_i, [_vp]),
     "feasthip_shifted_solve": (_i, [_vp, _d, _d, _i64, _vp, _vp, _ps]),
     "feasthip_shifted_solve_dev": (_i, [_vp, _d, _d, _i64, _vp, _vp, _ps]),

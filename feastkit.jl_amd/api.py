@@ -78,7 +78,8 @@ def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False, max_flops=
         panels = 2 * local * A.shape[0] * 64 * 16
         # the elimination costs 8 N kl (kl + ku) flop per node: beyond ~1e14 in all (seconds of MFMA time) a band this wide
         # is no longer the cheap way to a direct solve
-        flops = 8.0 * A.shape[0] * kl * (kl + ku) * local
+        # (or the multifrontal elimination's padded fronts, when the library's plan took that: blocked == 2)
+        flops = eng.direct_plan_flops() * local
         fits = bool((local + 1) * nbytes + panels <= 0.85 * free and flops <= max_flops)
     except FeastHipError:
         fits = False

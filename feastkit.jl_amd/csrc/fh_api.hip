@@ -366,6 +366,12 @@ extern "C" int feasthip_band_plan(feasthip_handle h, int* kl, int* ku, int64_t* 
     FH_CHECK(hipSetDevice(h->device));
     return fh_banded_plan(h, kl, ku, bytes_per_node, blocked);
 }
+extern "C" int feasthip_direct_plan_flops(feasthip_handle h, double* flops_per_node) {
+    if (!h) return FEASTHIP_ERROR_INTERNAL;
+    if (h->poisoned) { h->last_error = "handle poisoned by an earlier device failure: destroy it"; return FEASTHIP_ERROR_INTERNAL; }
+    FH_CHECK(hipSetDevice(h->device));
+    return fh_banded_plan_flops(h, flops_per_node);
+}
 
 extern "C" int feasthip_set_dense(feasthip_handle h, int64_t N, int is_complex, const void* A, int64_t lda,
                                   const void* B, int64_t ldb) {

@@ -189,6 +189,7 @@ void fh_banded_free(feasthip_ctx* h) {
     if (h->band_iperm) hipFree(h->band_iperm);
     h->band_perm = nullptr; h->band_iperm = nullptr;
     h->band_plan = 0; h->band_kl = 0; h->band_ku = 0;
+    fh_mf_free(h);
 }
 
 static int band_make_plan(feasthip_ctx* h) {
@@ -198,8 +199,9 @@ static int band_make_plan(feasthip_ctx* h) {
     if ((int64_t)h->host_rowptr.size() != N + 1) { h->last_error = "banded LU: no host pattern"; return FEASTHIP_ERROR_INTERNAL; }
     int kl0 = 0, ku0 = 0;
     fh_bandwidth(N, h->host_rowptr, h->host_col, nullptr, kl0, ku0);
-    const bool force_wide = getenv("FH_WBAND") && atoi(getenv("FH_WBAND")) != 0;     // read per plan: tests switch it
-    if (!force_wide && kl0 + ku0 <= FH_BAND_NARROW) {
+    const bool force_wide = getenv("FH_WBAND") && atoi(getenv("FH_WBAND")) != 0;     // read per plan: tests switch it (and it keeps the multifrontal plan out)
+    const int mf_mode = getenv("FH_MF") ? atoi(getenv("FH_MF")) : -1;                 // 0 never, 1 always (tests), else by predicted work
+    if (!force_wide && mf_mode != 1 && kl0 + ku0 <= FH_BAND_NARROW) {
         h->band_plan = 1; h->band_kl = kl0; h->band_ku = ku0;
         return 0;
     }
@@ -212,6 +214,30 @@ static int band_make_plan(feasthip_ctx* h) {
     if ((double)kl1 * (kl1 + ku1) >= (double)kl0 * (kl0 + ku0)) {
         for (int64_t i = 0; i < N; ++i) { perm[i] = (int)i; iperm[i] = (int)i; }
         kl1 = kl0; ku1 = ku0;
+    }
+    // Multifrontal plan (fh_mf.hpp, numeric phase in fh_dense.hip): fill confined to the fronts of a nested-dissection tree
+    // instead of the band.  Taken when its (padded) work is under half the band elimination's -- the band LU streams one
+    // long trailing update per block column, the fronts are many smaller batches -- complex128 factors only.
+    // FH_MF=0 never, FH_MF=1 always (tests); FH_MF_LEAF: largest leaf subset (default 64).
+    {
+        const int mode = mf_mode;
+        if (mode != 0 && !(force_wide && mode != 1) && h->factor_precision != 32 && (N >= 2048 || mode == 1)) {
+            const int leaf = getenv("FH_MF_LEAF") ? std::max(8, atoi(getenv("FH_MF_LEAF"))) : 64;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (fh_mf_make_plan(h, leaf) == 0) {
+                const double band_flops = 8.0 * (double)N * (double)kl1 * (double)(kl1 + ku1);
+                // (a front beyond 16 384 rows is outside the panel kernels' reach: such a pattern has no small separators anyway)
+                const bool take = fh_mf_max_front(h) <= 16384 && (mode == 1 || fh_mf_plan_flops(h) < 0.5 * band_flops);
+                if (getenv("FH_DEBUG_TIMING"))
+                    fprintf(stderr, "[feasthip] multifrontal plan (%.1f ms): %.3e flop and %.2f GB per node, band %.3e flop and %.2f GB -> %s\n",
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), fh_mf_plan_flops(h),
+                            fh_mf_store_bytes(h) / 1e9, band_flops, (double)fh_wband_elems((int)N, kl1, ku1) * sizeof(cplx) / 1e9, take ? "multifrontal" : "band");
+                if (take) { h->band_plan = 3; h->band_kl = kl1; h->band_ku = ku1; return 0; }
+                fh_mf_free(h);
+            } else {
+                h->last_error.clear();
+            }
+        }
     }
     FH_CHECK(hipMalloc((void**)&h->band_perm, N * sizeof(int)));
     FH_CHECK(hipMalloc((void**)&h->band_iperm, N * sizeof(int)));
@@ -226,6 +252,7 @@ static int band_make_plan(feasthip_ctx* h) {
 
 static size_t band_slot_bytes(feasthip_ctx* h) {
     const size_t N = (size_t)h->csr.N;
+    if (h->band_plan == 3) return fh_mf_store_bytes(h);
     if (h->band_plan == 2) return fh_wband_elems((int)N, h->band_kl, h->band_ku) * (h->band_prec == 32 ? sizeof(cplxf) : sizeof(cplx));
     return ((size_t)2 * h->band_kl + h->band_ku + 1) * N * sizeof(cplx);
 }
@@ -236,7 +263,7 @@ static int band_check(feasthip_ctx* h) {
     if (h->band_plan == 1) {
         const size_t lds = (size_t)(2 * h->band_kl + h->band_ku + 1) * sizeof(cplx);
         if (lds > 60000) { h->last_error = "banded LU: internal (narrow plan with a wide band)"; return FEASTHIP_ERROR_INTERNAL; }
-    } else if (h->band_kl > 12000) {
+    } else if (h->band_plan == 2 && h->band_kl > 12000) {
         h->last_error = "banded LU: band too wide after reordering (kl > 12000); use an iterative solver";
         return FEASTHIP_ERROR_FPM;
     }
@@ -257,7 +284,9 @@ static int band_ensure_slots(feasthip_ctx* h, int nslots) {
     const int missing = nslots - (int)h->band_factors.size();
     if (missing > 0) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)missing * (double)bytes > 0.92 * (double)free_b) {
+        // (multifrontal plan: the work arena and the substitution panels are transient buffers of about the factors' size again)
+        const double transient = h->band_plan == 3 ? (double)nslots * ((double)fh_mf_work_bytes(h) + 0.5 * (double)bytes) : 0.0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)missing * (double)bytes + transient > 0.92 * (double)free_b) {
             h->last_error = "banded LU: " + std::to_string(missing) + " factors of " + std::to_string(bytes >> 20) + " MiB do not fit the free device memory (" +
                             std::to_string(free_b >> 20) + " MiB)";
             return FEASTHIP_ERROR_MEMORY;
@@ -276,7 +305,7 @@ static int band_ensure_slots(feasthip_ctx* h, int nslots) {
     while ((int)h->band_factors.size() < nslots) {
         void* f = nullptr; int* pv = nullptr;
         if (hipMalloc(&f, bytes) != hipSuccess) { (void)hipGetLastError(); h->last_error = "hipMalloc(band factor)"; return FEASTHIP_ERROR_MEMORY; }
-        if (hipMalloc((void**)&pv, N * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); hipFree(f); h->last_error = "hipMalloc(band pivots)"; return FEASTHIP_ERROR_MEMORY; }
+        if (hipMalloc((void**)&pv, (h->band_plan == 3 ? fh_mf_pivot_ints(h) : N) * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); hipFree(f); h->last_error = "hipMalloc(band pivots)"; return FEASTHIP_ERROR_MEMORY; }
         h->band_factors.push_back(f); h->band_pivots.push_back(pv); h->band_valid.push_back(0); h->band_z.push_back(cmake(0, 0));
     }
     return 0;
@@ -314,6 +343,19 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
     const auto t_factor = std::chrono::steady_clock::now();
     void* p;
     int rc;
+    if (h->band_plan == 3) {
+        std::vector<void*> stores(nf);
+        std::vector<int*> pvs(nf);
+        for (int q = 0; q < nf; ++q) { stores[q] = h->band_factors[which[q]]; pvs[q] = h->band_pivots[which[q]]; }
+        if ((rc = fh_get_buf(h, "bd_z", nf * sizeof(cplx), &p))) return rc;
+        cplx* dz = (cplx*)p;
+        FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
+        if ((rc = fh_mf_factor(h, nf, stores.data(), pvs.data(), dz, info_out))) return rc;
+        if (getenv("FH_DEBUG_TIMING"))
+            fprintf(stderr, "[feasthip] multifrontal LU: %d factorisations in %.1f ms\n", nf,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_factor).count());
+        return 0;
+    }
     cplx** dabs; int** dpvs; int** dperms;
     if ((rc = band_pointer_arrays(h, which, &dabs, &dpvs, &dperms))) return rc;
     if ((rc = fh_get_buf(h, "bd_z", nf * sizeof(cplx), &p))) return rc;
@@ -356,6 +398,12 @@ static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<in
     const int nf = (int)slots.size();
     const int N = (int)h->csr.N;
     int rc;
+    if (h->band_plan == 3) {
+        std::vector<void*> stores(nf);
+        std::vector<int*> pvs(nf);
+        for (int q = 0; q < nf; ++q) { stores[q] = h->band_factors[slots[q]]; pvs[q] = h->band_pivots[slots[q]]; }
+        return fh_mf_solve(h, nf, stores.data(), pvs.data(), RHS, rhs_stride, Y, stride, ld, m);
+    }
     cplx** dabs; int** dpvs; int** dperms;
     if ((rc = band_pointer_arrays(h, slots, &dabs, &dpvs, &dperms))) return rc;
     if (h->band_plan == 2) {
@@ -425,6 +473,14 @@ int fh_banded_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* R
     return 0;
 }
 
+// real flops of ONE node's factorisation under the plan in force (band: 8 N kl (kl + ku); multifrontal: the padded fronts)
+int fh_banded_plan_flops(feasthip_ctx* h, double* flops) {
+    int rc = band_check(h);
+    if (rc && !h->band_plan) return rc;
+    if (flops) *flops = h->band_plan == 3 ? fh_mf_plan_flops(h) : 8.0 * (double)h->csr.N * (double)h->band_kl * (double)(h->band_kl + h->band_ku);
+    return rc;
+}
+
 // The band the direct solver would work on, and the device memory one factor takes (feasthip_band_plan)
 int fh_banded_plan(feasthip_ctx* h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked) {
     int rc = band_check(h);
@@ -432,6 +488,6 @@ int fh_banded_plan(feasthip_ctx* h, int* kl, int* ku, int64_t* bytes_per_node, i
     if (kl) *kl = h->band_kl;
     if (ku) *ku = h->band_ku;
     if (bytes_per_node) *bytes_per_node = (int64_t)band_slot_bytes(h);
-    if (blocked) *blocked = h->band_plan == 2 ? 1 : 0;
+    if (blocked) *blocked = h->band_plan == 3 ? 2 : (h->band_plan == 2 ? 1 : 0);      // 2: multifrontal (kl, ku: the band it replaced)
     return rc;
 }

@@ -10,3 +10,4 @@ int fh_banded_solve_nodes(feasthip_ctx* h, int ld, int m, int nodes, const std::
 int fh_banded_solve_single(feasthip_ctx* h, int ld, int m, cplx z, const cplx* RHS, cplx* Y, int* status, int64_t* nfact);
 void fh_banded_free(feasthip_ctx* h);
 int fh_banded_plan(feasthip_ctx* h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked);
+int fh_banded_plan_flops(feasthip_ctx* h, double* flops);

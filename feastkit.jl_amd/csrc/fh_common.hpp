@@ -197,6 +197,7 @@ struct feasthip_ctx {
     std::vector<int*> band_pivots;
     std::vector<int> band_valid;
     std::vector<cplx> band_z;
+    void* mf = nullptr;           // multifrontal plan of the sparse direct solver (fh_dense.hip: fh_mf_state), band_plan == 3
     std::vector<int> col_mask;    // feasthip_set_column_mask: columns with 0 are not iterated by the Krylov solvers
     int poisoned = 0;             // a Krylov deadline / queue fault returned with kernels possibly still queued: every later call fails fast
     int mask_live = 0;            // set only while a contour_apply call runs: the mask is one-shot and never reaches shifted_solve

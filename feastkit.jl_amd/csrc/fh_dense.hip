@@ -454,7 +454,9 @@ __device__ inline void lu_wave_argmax(double& best, int& bi) {
 // global memory once per sub-panel it participates in, instead of once per column.
 template <int R, int W, typename T>
 __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs, int* const* pivs, lu_geom g, int nr, int k0,
-                                                                    int nb, int* info) {
+                                                                    int nb, int* info, int pl) {
+    // pl: pivot limit -- rows >= pl are eliminated but never chosen as a pivot (pl = nr: LAPACK's partial pivoting; the
+    // multifrontal fronts pass the size of their fully-summed block)
     T* A = LUs[blockIdx.x];
     const int N = g.ld;                          // leading dimension; rows of the panel: [k0, nr)
     int* piv = pivs[blockIdx.x];
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                 int bi = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (rows[r] >= jj && rows[r] < nr) {
+                    if (rows[r] >= jj && rows[r] < pl) {
                         const double m = fabs(a[r][j].x) + fabs(a[r][j].y);
                         if (m > best) { best = m; bi = rows[r]; }
                     }
@@ -1611,11 +1613,11 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
                 const int nrows = N - k0;
                 const dim3 g(nf), b(LU_PANEL_THREADS);
                 if (!panel_in_registers(k0)) hipLaunchKernelGGL((k_lu_panel<T>), g, b, 0, h->stream, dlus, dpvs, N, k0, nb, dinfo);
-                else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
-                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
-                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
-                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
-                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo);
+                else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo, N);
+                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo, N);
+                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo, N);
+                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo, N);
+                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dlus, dpvs, geom, N, k0, nb, dinfo, N);
             }
             fh_prof_end(h);
             // interchanges inside the block column (left: finished L columns, right: still to eliminate)
@@ -2036,11 +2038,11 @@ static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** db
             const int nb = std::min(LU_NB, Kend - k0);
             const int nrows = nr - k0;
             const dim3 g(nf), b(LU_PANEL_THREADS);
-            if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
-            else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
-            else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
-            else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
-            else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo);
+            if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo, nr);
+            else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo, nr);
+            else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo, nr);
+            else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo, nr);
+            else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), g, b, 0, h->stream, dbases, dpvs, geom, nr, k0, nb, dinfo, nr);
             laswp(k0, nb, K0, k0, k0 + nb, Kend);              // inside the block column only
             if (k0 + nb < Kend) {
                 trsm(k0, nb, k0 + nb, Kend);
@@ -2151,4 +2153,532 @@ int fh_wband_solve(feasthip_ctx* h, int prec, int nf, void** dbases, int** dpvs,
                    cplx* Y, size_t stride, void* Yb, void* Zb, int ld, int m, int kl, int ku) {
     if (prec == 32) return wband_solve_t<cplxf>(h, nf, (cplxf**)dbases, dpvs, dperms, d_perm, RHS, rhs_stride, Y, stride, (cplxf*)Yb, (cplxf*)Zb, ld, m, kl, ku);
     return wband_solve_t<cplx>(h, nf, (cplx**)dbases, dpvs, dperms, d_perm, RHS, rhs_stride, Y, stride, (cplx*)Yb, (cplx*)Zb, ld, m, kl, ku);
+}
+
+// =======================================================================================
+// Multifrontal sparse LU (the reference's `lu(z*B - A)` on a SparseMatrixCSC is UMFPACK: src/sparse/feast_sparse.jl:334-342).
+// Symbolic phase: fh_mf.hpp (nested dissection, fronts, padded groups, maps; pure C++).  Numeric phase, here: the fronts
+// of one group -- (fronts of the group) x (quadrature nodes) dense matrices of ONE padded geometry (np fully-summed rows and
+// columns, nb boundary rows, order n = np + nb) -- are a batch for the dense LU kernels above:
+//   assemble     zero + identity on the pad pivots (k_mf_init), z B - A entries through the plan's assembly list
+//                (k_mf_assemble), the children's Schur complements through the extend-add maps (k_mf_extend_add; the two
+//                children of a parent one after the other, so the sums are reproducible)
+//   partial LU   the two-level right-looking LU above stopped after np columns, pivots searched among the rows < np only
+//                (k_lu_panel_reg's pivot limit); what is left in the trailing nb x nb block is the Schur complement
+//   store        the L block column (n x np, U11 inside), U12 (np x nb) and the inverted diagonal blocks go to the compact
+//                per-node factor store; the full n x n work matrices live in an arena only until their parents are assembled
+// Substitution (k_mf_fwd_* / k_mf_bwd_*): right-hand sides travel up the tree as front vectors (n x ld row-major panels, the
+// same extend-add maps), each group a batch for k_solve_diag[_inv] / k_solve_update; the solution travels down by gathers.
+// No atomics anywhere: bitwise reproducible.  complex128 only.
+// =======================================================================================
+#include "fh_mf.hpp"
+
+struct mf_kid {
+    long long child_work, parent_work;     // element offsets of the two front matrices inside one node's work arena
+    long long c_rhs_off;                   // rows: the child's group in the substitution panels
+    int n_c, np_c, nbnd, rel_off;
+    int c_slot, c_F, p_slot, pad;
+};
+struct mf_slot {                           // per front, in (group, slot) order
+    int npiv, nbnd, piv0, rel_off;
+    long long p_rhs_off;                   // parent's group in the substitution panels (rows), -1: root
+    int p_F, p_n, p_slot, pad;
+};
+
+struct fh_mf_state {
+    fh_mf::plan P;
+    int *d_asm_dst = nullptr, *d_asm_src = nullptr, *d_rel = nullptr, *d_perm = nullptr;
+    mf_kid* d_kids = nullptr;
+    mf_slot* d_slots = nullptr;
+    std::vector<size_t> slot_off;          // group -> first entry of d_slots
+    std::vector<size_t> kid_off[2];        // group, side -> first entry of d_kids
+    double band_flops = 0.0;
+};
+
+void fh_mf_free(feasthip_ctx* h) {
+    fh_mf_state* S = (fh_mf_state*)h->mf;
+    if (!S) return;
+    for (void* p : {(void*)S->d_asm_dst, (void*)S->d_asm_src, (void*)S->d_rel, (void*)S->d_perm, (void*)S->d_kids, (void*)S->d_slots}) if (p) (void)hipFree(p);
+    delete S;
+    h->mf = nullptr;
+}
+
+// Builds the plan from the host copy of the stored pattern.  Returns 0 and leaves h->mf set, or an error code (h->mf null).
+int fh_mf_make_plan(feasthip_ctx* h, int leaf) {
+    fh_mf_free(h);
+    const int N = (int)h->csr.N;
+    fh_mf_state* S = new fh_mf_state();
+    const int rc = fh_mf::make_plan(N, h->host_rowptr, h->host_col, h->csr.b_identity != 0, leaf, S->P);
+    if (rc) { delete S; h->last_error = "multifrontal plan: internal error " + std::to_string(rc); return FEASTHIP_ERROR_INTERNAL; }
+    const fh_mf::plan& P = S->P;
+    std::vector<mf_slot> slots;
+    std::vector<mf_kid> kids;
+    const int ng = (int)P.groups.size();
+    S->slot_off.assign(ng + 1, 0);
+    S->kid_off[0].assign(ng + 1, 0); S->kid_off[1].assign(ng + 1, 0);
+    for (int g = 0; g < ng; ++g) {
+        const fh_mf::group& G = P.groups[g];
+        S->slot_off[g] = slots.size();
+        for (int f : G.fronts) {
+            const fh_mf::front& F = P.fronts[f];
+            mf_slot s;
+            s.npiv = F.npiv; s.nbnd = F.nbnd; s.piv0 = F.piv0; s.rel_off = (int)F.bnd_off; s.pad = 0;
+            if (F.parent >= 0) {
+                const fh_mf::front& Pf = P.fronts[F.parent];
+                const fh_mf::group& Gp = P.groups[Pf.group];
+                s.p_rhs_off = (long long)Gp.rhs_off; s.p_F = (int)Gp.fronts.size(); s.p_n = Gp.n; s.p_slot = Pf.slot;
+            } else { s.p_rhs_off = -1; s.p_F = 0; s.p_n = 0; s.p_slot = 0; }
+            slots.push_back(s);
+        }
+        for (int side = 0; side < 2; ++side) {
+            S->kid_off[side][g] = kids.size();
+            for (int c : G.kids[side]) {
+                const fh_mf::front& C = P.fronts[c];
+                const fh_mf::group& Gc = P.groups[C.group];
+                const fh_mf::front& Pf = P.fronts[C.parent];
+                mf_kid k;
+                k.child_work = (long long)(Gc.work_off + (size_t)C.slot * Gc.work_per);
+                k.parent_work = (long long)(G.work_off + (size_t)Pf.slot * G.work_per);
+                k.c_rhs_off = (long long)Gc.rhs_off;
+                k.n_c = Gc.n; k.np_c = Gc.np; k.nbnd = C.nbnd; k.rel_off = (int)C.bnd_off;
+                k.c_slot = C.slot; k.c_F = (int)Gc.fronts.size(); k.p_slot = Pf.slot; k.pad = 0;
+                kids.push_back(k);
+            }
+        }
+    }
+    S->slot_off[ng] = slots.size();
+    // (kid_off[side][g + 1] is not the end of side's range: ranges are [kid_off[0][g], kid_off[1][g]) and [kid_off[1][g], next kid_off[0]))
+    S->kid_off[0][ng] = kids.size(); S->kid_off[1][ng] = kids.size();
+    if (P.bnd.size() > (size_t)0x7fffffff) { delete S; h->last_error = "multifrontal plan: boundary lists beyond int32"; return FEASTHIP_ERROR_MEMORY; }
+    auto up = [&](const void* src, size_t bytes, void** dst) -> bool {
+        if (bytes == 0) { *dst = nullptr; return true; }
+        if (hipMalloc(dst, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    h->mf = S;
+    if (!up(P.asm_dst.data(), P.asm_dst.size() * sizeof(int), (void**)&S->d_asm_dst) || !up(P.asm_src.data(), P.asm_src.size() * sizeof(int), (void**)&S->d_asm_src) ||
+        !up(P.rel.data(), P.rel.size() * sizeof(int), (void**)&S->d_rel) || !up(P.perm.data(), P.perm.size() * sizeof(int), (void**)&S->d_perm) ||
+        !up(kids.data(), kids.size() * sizeof(mf_kid), (void**)&S->d_kids) || !up(slots.data(), slots.size() * sizeof(mf_slot), (void**)&S->d_slots)) {
+        fh_mf_free(h);
+        h->last_error = "multifrontal plan: device allocation";
+        return FEASTHIP_ERROR_MEMORY;
+    }
+    return 0;
+}
+int fh_mf_max_front(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.max_n : 0; }
+double fh_mf_plan_flops(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.flops : 0.0; }
+size_t fh_mf_store_bytes(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.store_elems * sizeof(cplx) : 0; }
+size_t fh_mf_pivot_ints(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.piv_ints : 0; }
+size_t fh_mf_work_bytes(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.work_elems * sizeof(cplx) : 0; }
+
+// zero the work matrices of a group, 1 on the pad pivots
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_init(T* const* W, const mf_slot* slots, int F, int n, int np) {
+    const int m = blockIdx.y;
+    T* A = W[m];
+    const int npiv = slots[m % F].npiv;
+    const size_t total = (size_t)n * n;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int r = (int)(e % n), c = (int)(e / n);
+        A[e] = LU_MK((r == c && r >= npiv && r < np) ? 1.0 : 0.0, 0.0);
+    }
+}
+
+// entries of z B - A through the assembly list of one group (grid.y = node)
+template <typename VT, bool BIDENT, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_assemble(const int* __restrict__ dst, const int* __restrict__ src, size_t count, T* base, size_t node_stride,
+                                                           const VT* __restrict__ aval, const VT* __restrict__ bval, const cplx* z) {
+    T* A = base + (size_t)blockIdx.y * node_stride;
+    const cplx zz = z[blockIdx.y];
+    for (size_t q = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; q < count; q += (size_t)gridDim.x * FH_BLOCK) {
+        int d = dst[q];
+        const bool dg = d < 0;
+        if (dg) d = ~d;
+        const int k = src[q];
+        cplx v = cmake(0, 0);
+        if (k >= 0) {
+            if constexpr (sizeof(VT) == sizeof(cplx)) v = cmake(-aval[k].x, -aval[k].y); else v = cmake(-aval[k], 0.0);
+            if (!BIDENT) {
+                cplx b;
+                if constexpr (sizeof(VT) == sizeof(cplx)) b = cmake(bval[k].x, bval[k].y); else b = cmake(bval[k], 0.0);
+                cfma(v, zz, b);
+            }
+        }
+        if (dg) v = cadd(v, zz);
+        A[d] = cvt<T>(v);
+    }
+}
+
+// parent front += Schur complement of a child (grid.y = child, grid.z = node)
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_extend_add(const mf_kid* kids, T* base, size_t node_stride, const int* __restrict__ rel, int n_p) {
+    const mf_kid kd = kids[blockIdx.y];
+    const T* C = base + (size_t)blockIdx.z * node_stride + kd.child_work;
+    T* Pm = base + (size_t)blockIdx.z * node_stride + kd.parent_work;
+    const int* r = rel + kd.rel_off;
+    const int nb = kd.nbnd;
+    const size_t total = (size_t)nb * nb;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int i = (int)(e % nb), j = (int)(e / nb);
+        const T v = C[(size_t)(kd.np_c + i) + (size_t)(kd.np_c + j) * kd.n_c];
+        T* d = Pm + (size_t)r[i] + (size_t)r[j] * n_p;
+        *d = LU_MK(d->x + v.x, d->y + v.y);
+    }
+}
+
+// L block column (n x np, contiguous) and U12 (np x nb, leading dimension np) of a factored front -> factor store
+template <typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_store(T* const* W, T* const* S, int n, int np, int nb, size_t u12_off) {
+    const T* A = W[blockIdx.y];
+    T* D = S[blockIdx.y];
+    const size_t nl = (size_t)n * np, nu = (size_t)np * nb;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < nl + nu; e += (size_t)gridDim.x * FH_BLOCK) {
+        if (e < nl) D[e] = A[e];
+        else {
+            const size_t u = e - nl;
+            const int i = (int)(u % np), j = (int)(u / np);
+            D[u12_off + u] = A[(size_t)i + (size_t)(np + j) * n];
+        }
+    }
+}
+
+// ---- substitution: front vectors are row-major n x LD panels; group g's panels start at row rhs_off * nf, matrix m = node * F + slot
+// forward, step 1: Z[m] = [rhs rows of the pivots (unpermuted); 0]
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_load(const cplx* __restrict__ RHS, size_t rhs_stride, const int* __restrict__ perm, const mf_slot* slots, int F,
+                                                           cplx* Z, int n) {
+    const int m = blockIdx.y, s = m % F, node = m / F;
+    const mf_slot sl = slots[s];
+    const cplx* R = RHS + (size_t)node * rhs_stride;
+    cplx* z = Z + (size_t)m * n * LD;
+    const size_t total = (size_t)n * LD;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int r = (int)(e / LD), c = (int)(e % LD);
+        z[e] = r < sl.npiv ? R[(size_t)perm[sl.piv0 + r] * LD + c] : cmake(0, 0);
+    }
+}
+// forward, step 2: parent rows += the child's updated boundary rows (grid.y = child, grid.z = node)
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_add(const mf_kid* kids, const cplx* __restrict__ Ybase, cplx* Zp, const int* __restrict__ rel, int nf, int F_p, int n_p) {
+    const mf_kid kd = kids[blockIdx.y];
+    const int node = blockIdx.z;
+    const cplx* yc = Ybase + ((size_t)kd.c_rhs_off * nf + ((size_t)node * kd.c_F + kd.c_slot) * kd.n_c + kd.np_c) * LD;
+    cplx* zp = Zp + ((size_t)node * F_p + kd.p_slot) * n_p * LD;
+    const int* r = rel + kd.rel_off;
+    const size_t total = (size_t)kd.nbnd * LD;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int i = (int)(e / LD), c = (int)(e % LD);
+        cplx* d = zp + (size_t)r[i] * LD + c;
+        const cplx v = yc[e];
+        *d = cmake(d->x + v.x, d->y + v.y);
+    }
+}
+// forward, step 3: Y[m] = rows of Z[m] in pivot order (rows < np), boundary rows as they are
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_perm(int* const* pivs, const cplx* __restrict__ Z, cplx* Y, int n, int np) {
+    const int m = blockIdx.y;
+    const int* pr = pivs[m] + np;
+    const cplx* z = Z + (size_t)m * n * LD;
+    cplx* y = Y + (size_t)m * n * LD;
+    const size_t total = (size_t)n * LD;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int r = (int)(e / LD), c = (int)(e % LD);
+        y[e] = z[(size_t)(r < np ? pr[r] : r) * LD + c];
+    }
+}
+// backward, step 1: boundary rows of Y[m] = the parent's solution rows (pad rows zero)
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_bwd_load(const mf_slot* slots, int F, const cplx* Ybase, cplx* Y, const int* __restrict__ rel, int nf, int n, int np) {
+    const int m = blockIdx.y, s = m % F, node = m / F;
+    const mf_slot sl = slots[s];
+    cplx* y = Y + ((size_t)m * n + np) * LD;
+    const cplx* yp = sl.p_rhs_off >= 0 ? Ybase + ((size_t)sl.p_rhs_off * nf + ((size_t)node * sl.p_F + sl.p_slot) * sl.p_n) * LD : nullptr;
+    const int* r = rel + sl.rel_off;
+    const size_t total = (size_t)(n - np) * LD;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int i = (int)(e / LD), c = (int)(e % LD);
+        y[e] = (i < sl.nbnd && yp) ? yp[(size_t)r[i] * LD + c] : cmake(0, 0);
+    }
+}
+// backward, last step: the pivots' solution rows go to the caller's panel
+template <int LD>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_scatter(const mf_slot* slots, int F, const cplx* __restrict__ Y, const int* __restrict__ perm, cplx* OUT, size_t out_stride, int n) {
+    const int m = blockIdx.y, s = m % F, node = m / F;
+    const mf_slot sl = slots[s];
+    const cplx* y = Y + (size_t)m * n * LD;
+    cplx* o = OUT + (size_t)node * out_stride;
+    const size_t total = (size_t)sl.npiv * LD;
+    for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
+        const int r = (int)(e / LD), c = (int)(e % LD);
+        o[(size_t)perm[sl.piv0 + r] * LD + c] = y[e];
+    }
+}
+
+// pointer arrays of one call: per group and matrix (node-major, m = q * F + slot) the work matrix, the factor store, the
+// shifted U12 view and the pivots
+struct mf_ptrs { cplx** work; cplx** store; cplx** u12; int** piv; std::vector<size_t> off; };
+static int mf_pointer_arrays(feasthip_ctx* h, const fh_mf_state& S, int nf, void* const* stores, int* const* pivs, cplx* work, bool need_work, mf_ptrs& out) {
+    const fh_mf::plan& P = S.P;
+    const int ng = (int)P.groups.size();
+    out.off.assign(ng + 1, 0);
+    for (int g = 0; g < ng; ++g) out.off[g + 1] = out.off[g] + P.groups[g].fronts.size() * (size_t)nf;
+    const size_t tot = out.off[ng];
+    std::vector<cplx*> hw(tot), hs(tot), hu(tot);
+    std::vector<int*> hp(tot);
+    for (int g = 0; g < ng; ++g) {
+        const fh_mf::group& G = P.groups[g];
+        const size_t F = G.fronts.size();
+        const size_t u12 = (size_t)G.n * G.np + fh_mf::inv32_elems(G.np) + (G.inv128 ? fh_mf::inv128_elems(G.np) : 0);
+        for (int q = 0; q < nf; ++q)
+            for (size_t s = 0; s < F; ++s) {
+                const size_t m = out.off[g] + (size_t)q * F + s;
+                hw[m] = need_work ? work + (size_t)q * P.work_elems + G.work_off + s * G.work_per : nullptr;
+                hs[m] = (cplx*)stores[q] + G.store_off + s * G.store_per;
+                hu[m] = (cplx*)((uintptr_t)(hs[m] + u12) - (uintptr_t)((size_t)G.np * G.np * sizeof(cplx)));   // column c >= np of a leading-dimension-np view
+                hp[m] = pivs[q] + G.piv_off + s * 2 * (size_t)G.np;
+            }
+    }
+    void* p;
+    int rc;
+    if ((rc = fh_get_buf(h, "mf_ptrs", 4 * tot * sizeof(void*), &p))) return rc;
+    out.work = (cplx**)p; out.store = out.work + tot; out.u12 = out.store + tot; out.piv = (int**)(out.u12 + tot);
+    FH_CHECK(hipMemcpyAsync(out.work, hw.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(out.store, hs.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(out.u12, hu.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipMemcpyAsync(out.piv, hp.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static inline unsigned mf_blocks(size_t work, size_t per_block, unsigned cap) {
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(cap, (work + per_block - 1) / per_block));
+}
+
+// Factor nf shifted matrices z_q B - A into stores[q] / pivs[q].  info_out[q] != 0: a zero or non-finite pivot in some front.
+int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* dz, std::vector<int>& info_out) {
+    typedef cplx T;
+    fh_mf_state* S = (fh_mf_state*)h->mf;
+    if (!S) { h->last_error = "multifrontal LU: no plan"; return FEASTHIP_ERROR_INTERNAL; }
+    const fh_mf::plan& P = S->P;
+    const int ng = (int)P.groups.size();
+    void* p;
+    int rc;
+    if ((rc = fh_get_buf(h, "mf_work", (size_t)nf * P.work_elems * sizeof(T), &p))) return rc;
+    T* work = (T*)p;
+    mf_ptrs ptr;
+    if ((rc = mf_pointer_arrays(h, *S, nf, stores, pivs, work, true, ptr))) return rc;
+    const size_t tot = ptr.off[ng];
+    for (int g = 0; g < ng; ++g)
+        if (P.groups[g].fronts.size() * (size_t)nf > 65535) { h->last_error = "multifrontal LU: more than 65535 fronts x nodes in one group"; return FEASTHIP_ERROR_FPM; }
+    if ((rc = fh_get_buf(h, "mf_info", tot * sizeof(int), &p))) return rc;
+    int* dinfo = (int*)p;
+    FH_CHECK(hipMemsetAsync(dinfo, 0, tot * sizeof(int), h->stream));
+    static const bool m3_off = getenv("FH_LU_3M") && atoi(getenv("FH_LU_3M")) == 0;
+    const bool bid = h->csr.b_identity != 0, cz = h->csr.is_complex != 0;
+    for (int g = 0; g < ng; ++g) {
+        const fh_mf::group& G = P.groups[g];
+        const int F = (int)G.fronts.size(), nmat = F * nf, n = G.n, np = G.np, nb = G.nb;
+        T** W = ptr.work + ptr.off[g];
+        int** PV = ptr.piv + ptr.off[g];
+        T** ST = ptr.store + ptr.off[g];
+        const lu_geom geom{n, n, (size_t)n * n, 0};
+        // ---- assemble
+        fh_prof_begin(h, "mf_assemble");
+        hipLaunchKernelGGL((k_mf_init<T>), dim3(mf_blocks((size_t)n * n, 8 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, W, S->d_slots + S->slot_off[g], F, n, np);
+        {
+            const size_t cnt = G.asm_end - G.asm_begin;
+            if (cnt) {
+                const dim3 grid(mf_blocks(cnt, 4 * FH_BLOCK, 1024), nf), block(FH_BLOCK);
+                T* base = work + G.work_off;
+                const int* dd = S->d_asm_dst + G.asm_begin;
+                const int* ss = S->d_asm_src + G.asm_begin;
+                if (cz) {
+                    if (bid) hipLaunchKernelGGL((k_mf_assemble<cplx, true, T>), grid, block, 0, h->stream, dd, ss, cnt, base, P.work_elems, (const cplx*)h->csr.aval, (const cplx*)nullptr, dz);
+                    else hipLaunchKernelGGL((k_mf_assemble<cplx, false, T>), grid, block, 0, h->stream, dd, ss, cnt, base, P.work_elems, (const cplx*)h->csr.aval, (const cplx*)h->csr.bval, dz);
+                } else {
+                    if (bid) hipLaunchKernelGGL((k_mf_assemble<double, true, T>), grid, block, 0, h->stream, dd, ss, cnt, base, P.work_elems, (const double*)h->csr.aval, (const double*)nullptr, dz);
+                    else hipLaunchKernelGGL((k_mf_assemble<double, false, T>), grid, block, 0, h->stream, dd, ss, cnt, base, P.work_elems, (const double*)h->csr.aval, (const double*)h->csr.bval, dz);
+                }
+            }
+        }
+        for (int side = 0; side < 2; ++side) {
+            const size_t k0 = S->kid_off[side][g], k1 = side == 0 ? S->kid_off[1][g] : S->kid_off[0][g + 1];
+            if (k1 > k0) {
+                int nbmax = 0;
+                for (int c : G.kids[side]) nbmax = std::max(nbmax, P.fronts[c].nbnd);
+                if (nbmax > 0)
+                    hipLaunchKernelGGL((k_mf_extend_add<T>), dim3(mf_blocks((size_t)nbmax * nbmax, 8 * FH_BLOCK, 128), (unsigned)(k1 - k0), nf), dim3(FH_BLOCK), 0, h->stream,
+                                       S->d_kids + k0, work, P.work_elems, S->d_rel, n);
+            }
+        }
+        fh_prof_end(h);
+        // ---- partial LU: np columns, pivots among rows < np
+        fh_prof_begin(h, "mf_lu");
+        if (h->profiling) h->prof_work["mf_lu"] += fh_mf::partial_lu_flops(n, np) * (double)nmat;
+        auto laswp = [&](int p0, int cnt, int a0, int a1, int b0, int b1) {
+            const int ncols = (a1 - a0) + (b1 - b0);
+            if (ncols <= 0) return;
+            hipLaunchKernelGGL((k_lu_laswp<T>), dim3((ncols + FH_BLOCK - 1) / FH_BLOCK, nmat), dim3(FH_BLOCK), 0, h->stream, W, PV, n, p0, cnt, a0, a1, b0, b1);
+        };
+        auto trsm = [&](int k0, int c0, int c1) {
+            if (c1 <= c0) return;
+            hipLaunchKernelGGL((k_lu_trsm_mul<LU_NB, T>), dim3((c1 - c0 + FH_BLOCK / LU_NB - 1) / (FH_BLOCK / LU_NB), nmat), dim3(FH_BLOCK), 0, h->stream, W, geom, k0, c0, c1);
+        };
+        auto gemm = [&](int k0, int kd, int r0, int r1, int c0, int c1) {
+            if (r1 <= r0 || c1 <= c0) return;
+            const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
+            const int sw = std::min(8, TC);
+            const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
+            const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nmat);
+            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC);
+            else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC);
+        };
+        int* ginfo = dinfo + ptr.off[g];
+        for (int K0 = 0; K0 < np; K0 += SOLVE_KB) {
+            const int Kend = std::min(np, K0 + SOLVE_KB);
+            for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
+                const int nrows = n - k0;
+                const dim3 gg(nmat), bb(LU_PANEL_THREADS);
+                if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                else hipLaunchKernelGGL((k_lu_panel_reg<8, 2, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                laswp(k0, LU_NB, K0, k0, k0 + LU_NB, Kend);
+                if (k0 + LU_NB < Kend) {
+                    trsm(k0, k0 + LU_NB, Kend);
+                    gemm(k0, LU_NB, k0 + LU_NB, n, k0 + LU_NB, Kend);
+                }
+            }
+            laswp(K0, Kend - K0, 0, K0, Kend, n);
+            if (Kend < n) {
+                for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
+                    trsm(k0, Kend, n);
+                    if (k0 + LU_NB < Kend) gemm(k0, LU_NB, k0 + LU_NB, Kend, Kend, n);
+                }
+                gemm(K0, Kend - K0, Kend, n, Kend, n);
+            }
+        }
+        fh_prof_end(h);
+        // ---- store: L block column + U12, inverted diagonal blocks, row permutation of the pivot block
+        fh_prof_begin(h, "mf_store");
+        const size_t i32 = fh_mf::inv32_elems(np), u12 = (size_t)n * np + i32 + (G.inv128 ? fh_mf::inv128_elems(np) : 0);
+        hipLaunchKernelGGL((k_mf_store<T>), dim3(mf_blocks((size_t)n * np + (size_t)np * nb, 8 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, W, ST, n, np, nb, u12);
+        const lu_geom gs{n, np, (size_t)n * np, (size_t)n * np + i32};
+        hipLaunchKernelGGL((k_lu_invert_diag<LU_NB, T>), dim3(np / LU_NB, nmat), dim3(64), 0, h->stream, ST, gs);
+        if (G.inv128) {
+            const dim3 gi(SOLVE_KB / 16, (np + SOLVE_KB - 1) / SOLVE_KB, nmat);
+            hipLaunchKernelGGL((k_solve_diag<16, false, true, T>), gi, dim3(FH_BLOCK), 0, h->stream, ST, (T*)nullptr, (T*)nullptr, (size_t)0, gs, 0, 0);
+            hipLaunchKernelGGL((k_solve_diag<16, true, true, T>), gi, dim3(FH_BLOCK), 0, h->stream, ST, (T*)nullptr, (T*)nullptr, (size_t)0, gs, 0, 0);
+        }
+        hipLaunchKernelGGL(k_build_perm, dim3(nmat), dim3(FH_BLOCK), (size_t)np * sizeof(int), h->stream, PV, np);
+        fh_prof_end(h);
+    }
+    std::vector<int> hinfo(tot);
+    FH_CHECK(hipMemcpyAsync(hinfo.data(), dinfo, tot * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    FH_CHECK(hipStreamSynchronize(h->stream));
+    info_out.assign(nf, 0);
+    for (int g = 0; g < ng; ++g) {
+        const size_t F = P.groups[g].fronts.size();
+        for (int q = 0; q < nf; ++q)
+            for (size_t s = 0; s < F; ++s) if (hinfo[ptr.off[g] + (size_t)q * F + s] && !info_out[q]) info_out[q] = P.fronts[P.groups[g].fronts[s]].piv0 + 1;
+    }
+    return 0;
+}
+
+template <int LD>
+static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& ptr, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int m) {
+    typedef cplx T;
+    const fh_mf::plan& P = S->P;
+    const int ng = (int)P.groups.size();
+    const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
+    void* p;
+    int rc;
+    const size_t rows = P.rhs_rows * (size_t)nf;
+    if ((rc = fh_get_buf(h, "mf_y", rows * LD * sizeof(T), &p))) return rc;
+    T* Y = (T*)p;
+    if ((rc = fh_get_buf(h, "mf_z", rows * LD * sizeof(T), &p))) return rc;
+    T* Z = (T*)p;
+    fh_prof_begin(h, "mf_solve");
+    auto diag = [&](bool upper, T** ST, T* IN, T* OUTp, size_t stride, const lu_geom& gd, int K0, int kb, int nmat, bool inv128) {
+        const dim3 grid(cta, nmat), block(FH_BLOCK);
+        if (inv128) {
+            if (upper) hipLaunchKernelGGL((k_solve_diag_inv<LD, true, T>), grid, block, 0, h->stream, ST, IN, OUTp, stride, gd, K0, kb);
+            else hipLaunchKernelGGL((k_solve_diag_inv<LD, false, T>), grid, block, 0, h->stream, ST, IN, OUTp, stride, gd, K0, kb);
+        } else {
+            if (upper) hipLaunchKernelGGL((k_solve_diag<LD, true, false, T>), grid, block, 0, h->stream, ST, IN, OUTp, stride, gd, K0, kb);
+            else hipLaunchKernelGGL((k_solve_diag<LD, false, false, T>), grid, block, 0, h->stream, ST, IN, OUTp, stride, gd, K0, kb);
+        }
+    };
+    for (int g = 0; g < ng; ++g) {                               // forward: leaves first
+        const fh_mf::group& G = P.groups[g];
+        const int F = (int)G.fronts.size(), nmat = F * nf, n = G.n, np = G.np;
+        T* Yg = Y + G.rhs_off * (size_t)nf * LD;
+        T* Zg = Z + G.rhs_off * (size_t)nf * LD;
+        const size_t stride = (size_t)n * LD;
+        T** ST = ptr.store + ptr.off[g];
+        const unsigned gb = mf_blocks((size_t)n * LD, 4 * FH_BLOCK, 64);
+        hipLaunchKernelGGL((k_mf_fwd_load<LD>), dim3(gb, nmat), dim3(FH_BLOCK), 0, h->stream, RHS, rhs_stride, S->d_perm, S->d_slots + S->slot_off[g], F, Zg, n);
+        for (int side = 0; side < 2; ++side) {
+            const size_t k0 = S->kid_off[side][g], k1 = side == 0 ? S->kid_off[1][g] : S->kid_off[0][g + 1];
+            if (k1 > k0) {
+                int nbmax = 0;
+                for (int c : G.kids[side]) nbmax = std::max(nbmax, P.fronts[c].nbnd);
+                if (nbmax > 0)
+                    hipLaunchKernelGGL((k_mf_fwd_add<LD>), dim3(mf_blocks((size_t)nbmax * LD, 4 * FH_BLOCK, 64), (unsigned)(k1 - k0), nf), dim3(FH_BLOCK), 0, h->stream,
+                                       S->d_kids + k0, Y, Zg, S->d_rel, nf, F, n);
+            }
+        }
+        hipLaunchKernelGGL((k_mf_fwd_perm<LD>), dim3(gb, nmat), dim3(FH_BLOCK), 0, h->stream, ptr.piv + ptr.off[g], Zg, Yg, n, np);
+        const size_t i32 = fh_mf::inv32_elems(np);
+        const lu_geom gd{n, np, (size_t)n * np, (size_t)n * np + i32};      // diagonal solves: bounded by the pivot block
+        const lu_geom gu{n, n, (size_t)n * np, (size_t)n * np + i32};       // updates: all rows of the front
+        for (int K0 = 0; K0 < np; K0 += SOLVE_KB) {
+            const int kb = std::min(SOLVE_KB / LU_NB, (np - K0) / LU_NB);
+            const int r0 = K0 + LU_NB * kb;
+            diag(false, ST, Yg, Zg, stride, gd, K0, kb, nmat, G.inv128 != 0);
+            if (r0 < n)
+                hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((n - r0 + 63) / 64, nmat), dim3(FH_BLOCK), 0, h->stream, ST, Yg, Zg, stride, gu, K0, LU_NB * kb, r0, n, cta);
+        }
+    }
+    for (int g = ng - 1; g >= 0; --g) {                          // backward: root first
+        const fh_mf::group& G = P.groups[g];
+        const int F = (int)G.fronts.size(), nmat = F * nf, n = G.n, np = G.np, nb = G.nb;
+        T* Yg = Y + G.rhs_off * (size_t)nf * LD;
+        T* Zg = Z + G.rhs_off * (size_t)nf * LD;
+        const size_t stride = (size_t)n * LD;
+        T** ST = ptr.store + ptr.off[g];
+        const size_t i32 = fh_mf::inv32_elems(np);
+        const lu_geom gd{n, np, (size_t)n * np, (size_t)n * np + i32};
+        const lu_geom gu{n, n, (size_t)n * np, (size_t)n * np + i32};
+        if (nb > 0) {
+            hipLaunchKernelGGL((k_mf_bwd_load<LD>), dim3(mf_blocks((size_t)nb * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F,
+                               Y, Yg, S->d_rel, nf, n, np);
+            // z1 -= U12 x2: U12 through its leading-dimension-np view (columns np .. n)
+            const lu_geom g12{np, n, 0, 0};
+            hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((np + 63) / 64, nmat), dim3(FH_BLOCK), 0, h->stream, ptr.u12 + ptr.off[g], Zg, Yg, stride, g12, np, nb, 0, np, cta);
+        }
+        for (int K0 = ((np - 1) / SOLVE_KB) * SOLVE_KB; K0 >= 0; K0 -= SOLVE_KB) {
+            const int kb = std::min(SOLVE_KB / LU_NB, (np - K0) / LU_NB);
+            diag(true, ST, Zg, Yg, stride, gd, K0, kb, nmat, G.inv128 != 0);
+            if (K0 > 0)
+                hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((K0 + 63) / 64, nmat), dim3(FH_BLOCK), 0, h->stream, ST, Zg, Yg, stride, gu, K0, LU_NB * kb, 0, K0, cta);
+        }
+        hipLaunchKernelGGL((k_mf_scatter<LD>), dim3(mf_blocks((size_t)np * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F, Yg,
+                           S->d_perm, OUT, out_stride, n);
+    }
+    fh_prof_end(h);
+    return 0;
+}
+
+// OUT[q] = (z_q B - A)^-1 RHS[q] with the factors of fh_mf_factor.  Panels row-major N x ld; rhs_stride = 0: one shared panel.
+int fh_mf_solve(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int ld, int m) {
+    fh_mf_state* S = (fh_mf_state*)h->mf;
+    if (!S) { h->last_error = "multifrontal LU: no plan"; return FEASTHIP_ERROR_INTERNAL; }
+    mf_ptrs ptr;
+    int rc;
+    if ((rc = mf_pointer_arrays(h, *S, nf, stores, pivs, nullptr, false, ptr))) return rc;
+    if (ld == 16) return mf_solve_ld<16>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
+    if (ld == 32) return mf_solve_ld<32>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
+    return mf_solve_ld<64>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
 }

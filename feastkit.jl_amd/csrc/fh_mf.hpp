@@ -290,6 +290,7 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
                     // a front joins the group while the padded work of the whole group stays within 1.6 x the exact work
                     // (always for tiny fronts: below ~2e7 flop a front costs less than the launches of a group of its own)
                     if (j > i && padded > 1.6 * ex2 && padded - ex2 > 2e7 * (double)(j - i + 1)) break;
+                    if (j - i >= 2048) break;                    // (fronts x quadrature nodes is a grid dimension)
                     npm = std::max(npm, F.npiv); nbm = std::max(nbm, F.nbnd); exact = ex2;
                 }
                 G.np = round_up(npm, 32); G.nb = round_up(nbm, 16); G.n = G.np + G.nb;

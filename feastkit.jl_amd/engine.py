@@ -431,6 +431,12 @@ class HipEngine:
         self._chk(self.lib.feasthip_band_plan(self.h, C.byref(kl), C.byref(ku), C.byref(nbytes), C.byref(blocked)))
         return kl.value, ku.value, nbytes.value, blocked.value
 
+    def direct_plan_flops(self):
+        """real flops of one node's factorisation under the direct solver's plan (band LU or multifrontal)."""
+        fl = C.c_double(0.0)
+        self._chk(self.lib.feasthip_direct_plan_flops(self.h, C.byref(fl)))
+        return fl.value
+
     def last_node_iterations(self, n):
         out = np.zeros(max(1, n), dtype=np.int32)
         self._chk(self.lib.feasthip_last_node_iterations(self.h, _np_ptr(out), int(n)))

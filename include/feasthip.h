@@ -200,10 +200,15 @@ int  feasthip_set_column_mask(feasthip_handle h, int64_t m, const int* mask);
 int  feasthip_release_factors(feasthip_handle h);
 
 /* The band FEASTHIP_SOLVER_BANDED would eliminate for the current CSR problem (after its reordering) and the device memory
- * of ONE node's factor; *blocked = 1 when the blocked band LU on the dense kernels is used.  A host shim uses it to decide
+ * of ONE node's factor; *blocked = 1 when the blocked band LU on the dense kernels is used (2: multifrontal, below).  A host shim uses it to decide
  * between the direct and the iterative solvers (the reference decides by keyword only: src/sparse/feast_sparse.jl:249-252).
  * Returns 0, FEASTHIP_ERROR_FPM when no CSR problem is set or the band is beyond the solver's reach.                     */
 int  feasthip_band_plan(feasthip_handle h, int* kl, int* ku, int64_t* bytes_per_node, int* blocked);
+/* Real flops of ONE node's factorisation under the plan feasthip_band_plan reports (*blocked = 2: the multifrontal
+ * elimination on a nested-dissection tree, the counterpart of the reference's UMFPACK call src/sparse/feast_sparse.jl:334-342,
+ * taken when its work is under half the band elimination's; kl / ku are then the band it replaced and bytes_per_node the
+ * multifrontal factors).                                                                                                 */
+int  feasthip_direct_plan_flops(feasthip_handle h, double* flops_per_node);
 
 int  feasthip_set_solver(feasthip_handle h, int kind, double rtol, double atol, int maxit,
                          int restart, int factor_precision, int cache_factors);
