@@ -58,9 +58,17 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30, dense_limit=12288)
 _DIRECT_FLOPS = float(os.environ.get("FEASTKIT_DIRECT_FLOPS", "0"))
 
 
+def _direct_label(eng):
+    """what FEASTHIP_SOLVER_BANDED runs for the problem set on the engine (feasthip_band_plan: 2 = multifrontal)."""
+    try:
+        return "multifrontal LU on a nested-dissection tree" if eng.band_plan()[3] == 2 else "band LU after reverse Cuthill-McKee"
+    except Exception:
+        return "band LU after reverse Cuthill-McKee"
+
+
 def _band_direct_fits(eng, A, B, nodes, group=None, complexify=False, max_flops=1e14):
-    """True when the sparse direct solver for general patterns (reverse Cuthill-McKee + blocked band LU on the dense
-    kernels, FEASTHIP_SOLVER_BANDED) can hold one factor per local quadrature node in the free device memory.  Sets the
+    """True when the sparse direct solver for general patterns (multifrontal LU on a nested-dissection tree, or reverse
+    Cuthill-McKee + blocked band LU on the dense kernels: FEASTHIP_SOLVER_BANDED) can hold one factor per local quadrature node in the free device memory.  Sets the
     problem on the engine (a later set_problem with the same matrices is free: content fingerprint)."""
     import torch
     if complexify:
@@ -224,7 +232,7 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
             # default -- a direct factorisation per node, exact solves, two or three loops -- is then also the faster one
             # (measured: DESIGN.md section 5); wider bands keep the Krylov fast path with the direct solver as its fallback
             solver = "banded"
-            substituted = {"requested": "direct", "used": "band LU after reverse Cuthill-McKee"}
+            substituted = {"requested": "direct", "used": _direct_label(eng)}
             if fp is not None and fp[0] and fp[1] is not False:
                 eng._checked = {"fp": fp, "nodes": int(fpm[2]), "direct": solver}
         elif solver == "krylov":
@@ -299,7 +307,7 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         res = feast_hip_hermitian(eng, A, B, Emin, Emax, M0, fpm, solver="banded", solver_tol=solver_tol,
                                   real_projection=real_projection, inner_precision=inner_precision, group=group, Q0=Q0,
                                   contour=contour, eps_floor=float(np.sqrt(np.finfo(np.float32).eps)) if single else 0.0)
-        substituted = dict(substituted, fallback="band LU after reverse Cuthill-McKee", krylov_info=krylov_info,
+        substituted = dict(substituted, fallback=_direct_label(eng), krylov_info=krylov_info,
                            krylov_loops=krylov_loops)
     if substituted is not None and isinstance(res.stats, dict):
         res.stats["solver_substitution"] = substituted
@@ -344,7 +352,7 @@ def feast_general(A, B=None, center=0.0, radius=1.0, *, M0=10, fpm=None, backend
             engine = _engine(engine, device)
             if _band_direct_fits(engine, A, B, int(fpm[8]), group, complexify=True):
                 solver = "banded"
-                substituted = {"requested": "direct", "used": "band LU after reverse Cuthill-McKee"}
+                substituted = {"requested": "direct", "used": _direct_label(engine)}
             else:
                 solver = "bicgstab"
                 substituted = {"requested": "direct", "used": solver, "warm_start": False, "inner_rtol": None,

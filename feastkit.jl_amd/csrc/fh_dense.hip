@@ -452,16 +452,19 @@ __device__ inline void lu_wave_argmax(double& best, int& bi) {
 //      except the row interchange of the other panel columns.
 // Pivot rule as k_lu_panel (LAPACK IZAMAX).  Each panel entry is read from and written to
 // global memory once per sub-panel it participates in, instead of once per column.
-template <int R, int W, typename T>
-__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs, int* const* pivs, lu_geom g, int nr, int k0,
+// NT: threads per workgroup.  1024 for the dense and band factorisations (one matrix per CU, every wave slot taken); the
+// multifrontal fronts of <= 256 / 512 rows come in batches of thousands and take 256 / 512 threads, so that four / two of
+// them share a CU instead of one with three quarters of its lanes idle.
+template <int R, int W, typename T, int NT = 1024>
+__global__ __launch_bounds__(NT) void k_lu_panel_reg(T* const* LUs, int* const* pivs, lu_geom g, int nr, int k0,
                                                                     int nb, int* info, int pl) {
     // pl: pivot limit -- rows >= pl are eliminated but never chosen as a pivot (pl = nr: LAPACK's partial pivoting; the
     // multifrontal fronts pass the size of their fully-summed block)
     T* A = LUs[blockIdx.x];
     const int N = g.ld;                          // leading dimension; rows of the panel: [k0, nr)
     int* piv = pivs[blockIdx.x];
-    __shared__ double wmax[LU_PANEL_THREADS / 64];
-    __shared__ int widx[LU_PANEL_THREADS / 64];
+    __shared__ double wmax[NT / 64];
+    __shared__ int widx[NT / 64];
     __shared__ T rowA[W], rowB[W];
     __shared__ T Lsm[LU_NB][LU_NB + 1];
     __shared__ T Us[LU_NB][W];
@@ -469,18 +472,18 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
     const int kend = k0 + nb;
     int rows[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) rows[r] = k0 + t + LU_PANEL_THREADS * r;
+    for (int r = 0; r < R; ++r) rows[r] = k0 + t + NT * r;
 
     for (int c0 = k0; c0 < kend; c0 += W) {
         const int pc = c0 - k0;                      // previous panel columns
         const int wact = min(W, kend - c0);
         // ---- 1. U part: Us = L11^-1 A[k0:c0, c0:c0+wact]
         if (pc > 0) {
-            for (int e = t; e < pc * pc; e += LU_PANEL_THREADS) {
+            for (int e = t; e < pc * pc; e += NT) {
                 int i = e % pc, j = e / pc;
                 Lsm[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
             }
-            for (int e = t; e < pc * wact; e += LU_PANEL_THREADS) {
+            for (int e = t; e < pc * wact; e += NT) {
                 int i = e % pc, w = e / pc;
                 Us[i][w] = A[(size_t)(c0 + w) * N + k0 + i];
             }
@@ -488,15 +491,15 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
             // forward substitution with one wave per sub-panel column (W <= 16 waves): lane = row of the block, the
             // solved component is broadcast by shuffle and every later row updates itself -- pc short steps instead
             // of pc^2/2 dependent operations of a single thread
-            if (wave < wact) {
-                T x = lane < pc ? Us[lane][wave] : LU_MK(0, 0);
+            for (int wc = wave; wc < wact; wc += NT / 64) {
+                T x = lane < pc ? Us[lane][wc] : LU_MK(0, 0);
                 for (int i = 0; i + 1 < pc; ++i) {
                     const T xi = LU_MK(lu_readlane(x.x, i), lu_readlane(x.y, i));
                     if (lane > i && lane < pc) x = csub(x, cmul(Lsm[lane][i], xi));
                 }
                 if (lane < pc) {
-                    Us[lane][wave] = x;
-                    A[(size_t)(c0 + wave) * N + k0 + lane] = x;
+                    Us[lane][wc] = x;
+                    A[(size_t)(c0 + wc) * N + k0 + lane] = x;
                 }
             }
             __syncthreads();
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
                 __syncthreads();
                 best = wmax[0]; bi = widx[0];
 #pragma unroll
-                for (int q = 1; q < LU_PANEL_THREADS / 64; ++q) {
+                for (int q = 1; q < NT / 64; ++q) {
                     const double o = wmax[q];
                     const int oi = widx[q];
                     if (o > best || (o == best && oi < bi)) { best = o; bi = oi; }
@@ -637,13 +640,13 @@ __global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel_reg(T* const* LUs
     // ---- inverse of the unit-lower diagonal block, for the U block row (k_lu_trsm_mul): column c of L11^-1 by forward
     // substitution on e_c, one wave per column, lane = row, the solved component broadcast by shuffle
     if (nb == LU_NB) {
-        for (int e = t; e < LU_NB * LU_NB; e += LU_PANEL_THREADS) {
+        for (int e = t; e < LU_NB * LU_NB; e += NT) {
             const int i = e % LU_NB, j = e / LU_NB;
             Lsm[i][j] = A[(size_t)(k0 + j) * N + k0 + i];
         }
         __syncthreads();
         T* inv = A + g.inv32 + (size_t)(k0 / LU_NB) * 2 * LU_NB * LU_NB;
-        for (int c = wave; c < LU_NB; c += LU_PANEL_THREADS / 64) {
+        for (int c = wave; c < LU_NB; c += NT / 64) {
             T x = LU_MK(lane == c ? 1.0 : 0.0, 0.0);
             for (int i = c; i + 1 < LU_NB; ++i) {
                 const T xi = LU_MK(lu_readlane(x.x, i), lu_readlane(x.y, i));
@@ -860,11 +863,16 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, i
     T* A = LUs[blockIdx.y];
     __shared__ T Us[KC][64];
     const int t = threadIdx.x;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int SR = (TR + 7) >> 3;
-    const int sw = min(8, TC);
-    const int st = (slot / (8 * sw)) * 8 + xcd, within = slot % (8 * sw);
-    const int tr = (st % SR) * 8 + (within & 7), tc = (st / SR) * sw + (within >> 3);
+    int tr, tc;
+    if (gridDim.x == (unsigned)(TR * TC)) {     // compact grid (small products in large batches: the multifrontal fronts) -- no idle workgroups
+        tr = blockIdx.x % TR; tc = blockIdx.x / TR;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int SR = (TR + 7) >> 3;
+        const int sw = min(8, TC);
+        const int st = (slot / (8 * sw)) * 8 + xcd, within = slot % (8 * sw);
+        tr = (st % SR) * 8 + (within & 7); tc = (st / SR) * sw + (within >> 3);
+    }
     if (tr >= TR || tc >= TC) return;
     const int i0 = r0 + tr * 64, cc0 = c0 + tc * 64;
     const int lane = t & 63, wave = t >> 6;
@@ -2529,7 +2537,10 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
             const int TR = (r1 - r0 + 63) / 64, TC = (c1 - c0 + 63) / 64;
             const int sw = std::min(8, TC);
             const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
-            const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nmat);
+            const int full = ((nsuper + 7) / 8) * 8 * 8 * sw;
+            // the XCD-aware super-tile order pays on long trailing updates; on a 3 x 3 tile product of 12 000 fronts its idle
+            // workgroups were 95 % of the launch (51 ms for one k = 32 update of the leaf group)
+            const dim3 grid(nmat > 64 || 2 * TR * TC <= full ? TR * TC : full, nmat);
             if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC);
             else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC);
         };
@@ -2539,7 +2550,9 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
             for (int k0 = K0; k0 < Kend; k0 += LU_NB) {
                 const int nrows = n - k0;
                 const dim3 gg(nmat), bb(LU_PANEL_THREADS);
-                if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                if (nrows <= 256) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T, 256>), gg, dim3(256), 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                else if (nrows <= 512) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T, 512>), gg, dim3(512), 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
+                else if (nrows > 8 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<16, 1, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
                 else if (nrows <= LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<1, 16, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
                 else if (nrows <= 2 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<2, 8, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);
                 else if (nrows <= 4 * LU_PANEL_THREADS) hipLaunchKernelGGL((k_lu_panel_reg<4, 4, T>), gg, bb, 0, h->stream, W, PV, geom, n, k0, LU_NB, ginfo, np);

@@ -282,16 +282,22 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
                 int npm = 0, nbm = 0;
                 double exact = 0.0;
                 size_t j = i;
+                // A group costs (panel steps) x (latency of one step: a chain of small launches, ~0.2 ms whatever the batch)
+                // + (padded flops) / (MFMA rate); in flops per quadrature node one step is worth about step_flops.  A front
+                // joins while that is cheaper than a group of its own.
+                const double step_flops = 2.5e8;
+                double cost = 0.0;
                 for (; j < fs.size(); ++j) {
                     const front& F = P.fronts[fs[j]];
                     const int np2 = round_up(std::max(npm, F.npiv), 32), nb2 = round_up(std::max(nbm, F.nbnd), 16);
-                    const double ex2 = exact + partial_lu_flops(F.npiv + F.nbnd, F.npiv);
-                    const double padded = (double)(j - i + 1) * partial_lu_flops(np2 + nb2, np2);
-                    // a front joins the group while the padded work of the whole group stays within 1.6 x the exact work
-                    // (always for tiny fronts: below ~2e7 flop a front costs less than the launches of a group of its own)
-                    if (j > i && padded > 1.6 * ex2 && padded - ex2 > 2e7 * (double)(j - i + 1)) break;
+                    const double merged = (np2 / 32) * step_flops + (double)(j - i + 1) * partial_lu_flops(np2 + nb2, np2);
+                    const int np1 = round_up(F.npiv, 32), nb1 = round_up(F.nbnd, 16);
+                    const double alone = (np1 / 32) * step_flops + partial_lu_flops(np1 + nb1, np1);
+                    if (j > i && merged > cost + alone) break;
                     if (j - i >= 2048) break;                    // (fronts x quadrature nodes is a grid dimension)
-                    npm = std::max(npm, F.npiv); nbm = std::max(nbm, F.nbnd); exact = ex2;
+                    npm = std::max(npm, F.npiv); nbm = std::max(nbm, F.nbnd);
+                    exact += partial_lu_flops(F.npiv + F.nbnd, F.npiv);
+                    cost = merged;
                 }
                 G.np = round_up(npm, 32); G.nb = round_up(nbm, 16); G.n = G.np + G.nb;
                 G.fronts.assign(fs.begin() + i, fs.begin() + j);

@@ -260,7 +260,7 @@ def test_default_call_interior_interval_full_size(engine, switch, monkeypatch):
     if switch == "0":
         assert "fallback" not in sub and min(r.stats["contour_policy"]["fpm18_per_loop"]) > 100
     else:
-        assert sub.get("fallback", "").startswith("band LU") and sub["krylov_loops"] <= 6 and r.loop <= 3
+        assert sub.get("fallback", "").split()[0] in ("band", "multifrontal") and sub["krylov_loops"] <= 6 and r.loop <= 3
 
 
 _PENCILS = {"diag_mass_3d": ((50, 40, 25), "diag_mass"), "stiff_mass_3d": ((50, 40, 25), "stiff_mass"), "diag_mass_2d": ((400, 125), "diag_mass")}

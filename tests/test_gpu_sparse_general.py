@@ -111,7 +111,7 @@ def test_sparse_general_default_call_large_maps_to_band_direct(engine):
     A = _corner_coupled_diag(_clustered_spectrum(N))
     assert fk.api._sparse_direct_solver(A, None, 16) == "krylov"             # not a narrow band as stored, too large for dense
     r = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine)
-    assert r.stats["solver_substitution"]["used"] == "band LU after reverse Cuthill-McKee"
+    assert r.stats["solver_substitution"]["used"].split()[0] in ("band", "multifrontal")
     assert r.info == 0 and r.M == 6 and r.stats["krylov_iterations"] == 0 and r.stats["factorizations"] == 16
     kl, ku, nbytes, blocked = engine.band_plan()
     assert kl + ku <= 64                    # (the ingest renumbering or the band plan's own: either way a narrow band again)

@@ -15,14 +15,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture
-def force_blocked():
-    old = os.environ.get("FH_WBAND")
-    os.environ["FH_WBAND"] = "1"
-    yield
-    if old is None:
-        del os.environ["FH_WBAND"]
-    else:
-        os.environ["FH_WBAND"] = old
+def force_blocked(monkeypatch):
+    """the blocked band plan whatever the band width (and no multifrontal plan: tests/test_gpu_multifrontal.py has those)"""
+    monkeypatch.setenv("FH_WBAND", "1")
+    monkeypatch.setenv("FH_MF", "0")
 
 
 def random_pencil(n, band, density, seed, cplx, symmetric_pattern):
@@ -77,9 +73,10 @@ def test_blocked_band_solve_matches_superlu(engine, force_blocked, n, band, dens
     check_solve(engine, A, None, -0.2 + 0.05j, m)
 
 
-def test_blocked_band_takes_scrambled_order(engine):
+def test_blocked_band_takes_scrambled_order(engine, monkeypatch):
     """A narrow band hidden by a random symmetric permutation: the plan must find it again (reverse Cuthill-McKee) and
     the result must come back in the caller's order."""
+    monkeypatch.setenv("FH_MF", "0")
     n = 3000
     A0, B0 = random_pencil(n, 20, 0.4, 3, True, True)
     p = np.random.default_rng(1).permutation(n)
@@ -93,9 +90,10 @@ def test_blocked_band_takes_scrambled_order(engine):
     check_solve(engine, A, B, 0.5 + 0.5j, 24)
 
 
-def test_blocked_band_contour_apply_and_cache(engine):
+def test_blocked_band_contour_apply_and_cache(engine, monkeypatch):
     """3-D stencil in lexicographic order (band 2 x 30 x 20, beyond the narrow-band window): the sweep of a half contour
     against SuperLU, factors cached across sweeps."""
+    monkeypatch.setenv("FH_MF", "0")
     A, B, _ = workloads.laplacian_3d_pencil(30, 20, 12)
     n = A.shape[0]
     engine.set_problem(A, B)
@@ -162,7 +160,7 @@ def test_default_call_falls_back_to_the_direct_solver(engine):
         warnings.simplefilter("ignore")
         res = fk.feast(A, B, (mid - r, mid + r), M0=32, fpm=fpm, engine=engine)
     sub = res.stats["solver_substitution"]
-    assert sub["used"] == "cocg" and sub["fallback"].startswith("band LU") and sub["krylov_info"] == 5 and sub["krylov_loops"] <= 8
+    assert sub["used"] == "cocg" and sub["fallback"].split()[0] in ("band", "multifrontal") and sub["krylov_info"] == 5 and sub["krylov_loops"] <= 8
     assert res.info == 0 and res.M == 20
     assert np.abs(np.sort(res.lambda_) - inside).max() <= 1e-10
 
@@ -247,7 +245,7 @@ def test_sparse_general_direct_beyond_the_dense_window():
     assert inside.size == 21
     fpm = fk.feastinit(); fpm[8] = 16
     res = fk.feast_general(A, None, 0.0, radius, M0=inside.size, fpm=fpm)
-    assert res.stats["solver_substitution"]["used"].startswith("band LU") and res.stats["factorizations"] == 16
+    assert res.stats["solver_substitution"]["used"].split()[0] in ("band", "multifrontal") and res.stats["factorizations"] == 16
     assert res.info == 0 and res.M == inside.size
     key = lambda z: (round(z.real, 8), round(z.imag, 8))
     assert np.allclose(sorted(res.lambda_, key=key), sorted(inside, key=key), atol=1e-9)
