@@ -123,12 +123,13 @@ def test_sparse_general_default_call_large_maps_to_band_direct(engine):
     assert res.max() <= 1e-10
 
 
-def test_sparse_general_default_call_large_maps_to_krylov(engine):
+def test_sparse_general_default_call_large_maps_to_krylov(engine, monkeypatch):
     """A pattern no renumbering can make a band of (a full row and column) at N = 14 000: beyond the dense window and the
-    band solver's reach, the default maps to batched BiCGStab with the reference's iterative settings (zero guess,
-    rtol = atol = 10^-fpm[3], 500 iterations), recorded in stats and warned once.  The bulk of the spectrum lies in a disc
-    AWAY from the contour (centre 10, radius 2) with six eigenvalues inside it: z - A then has a clustered spectrum off
-    the origin plus six outliers and BiCGStab converges in a few dozen iterations."""
+    BAND solver's reach (FH_MF=0: no multifrontal plan), the default maps to batched BiCGStab with the reference's iterative
+    settings (zero guess, rtol = atol = 10^-fpm[3], 500 iterations), recorded in stats and warned once.  The bulk of the
+    spectrum lies in a disc AWAY from the contour (centre 10, radius 2) with six eigenvalues inside it: z - A then has a
+    clustered spectrum off the origin plus six outliers and BiCGStab converges in a few dozen iterations."""
+    monkeypatch.setenv("FH_MF", "0")
     N = 14000
     A = _arrow_coupled_diag(_clustered_spectrum(N))
     assert fk.api._sparse_direct_solver(A, None, 16) == "krylov"
@@ -147,6 +148,23 @@ def test_sparse_general_default_call_large_maps_to_krylov(engine):
     assert res.max() <= 1e-10
     rg = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine, solver="gmres")
     assert rg.info == 0 and np.allclose(sorted(rg.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-9)
+
+
+def test_sparse_general_arrow_pattern_takes_the_multifrontal_solver(engine):
+    """The same kind of arrow pattern with the library's own choice: no band, but a one-vertex separator -- the multifrontal
+    plan eliminates it like the reference's UMFPACK call would, and the default `solver=:direct` is a direct solve again
+    (same loops as the oracle's sparse LU per node, no Krylov iterations)."""
+    N = 14000
+    A = _arrow_coupled_diag(_clustered_spectrum(N, seed=13))      # (another matrix: the engine keeps the plan of one it holds)
+    r = fk.feast_general(A, None, 0.0, 0.8, M0=6, fpm=fpm_with(f8=16), engine=engine)
+    assert r.stats["solver_substitution"]["used"].startswith("multifrontal")
+    assert r.info == 0 and r.M == 6 and r.stats["krylov_iterations"] == 0 and r.stats["factorizations"] == 16
+    o = fo.feast_general(A, None, 0.0, 0.8, 6, ne=16)
+    assert o.info == 0 and o.M == 6
+    assert np.allclose(sorted(r.lambda_, key=ckey), sorted(o.lam, key=ckey), atol=1e-10)
+    assert r.loop == o.loop and r.epsout <= 1e-11
+    res = np.linalg.norm(A @ r.q - r.q * r.lambda_, axis=0) / np.linalg.norm(r.q, axis=0)
+    assert res.max() <= 1e-10
 
 
 @pytest.mark.parametrize("generalized", [True, False])
