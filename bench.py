@@ -487,7 +487,7 @@ def main():
                         "handle, matrix ingest + upload inside the time; ms_per_call / value: a repeated call, the engine recognises the "
                         "resident matrices by a content fingerprint (a pass over their arrays, inside the time) and skips the ingest"}
             # the reference's own default for this input, a DIRECT solve per node (UMFPACK, src/sparse/feast_sparse.jl:339):
-            # here reverse Cuthill-McKee + blocked band LU on the dense kernels, factors cached per node
+            # here the multifrontal LU on a nested-dissection tree (or, FH_MF=0, reverse Cuthill-McKee + blocked band LU), factors cached per node
             try:
                 fpm_b = fk.feastinit(); fpm_b[2] = NE
                 # a fresh ingest, so that the band plan (pattern scan + reverse Cuthill-McKee on the host) is made inside
@@ -507,6 +507,7 @@ def main():
                 dtb2 = time.perf_counter() - t1
                 okb = db.info == 0 and db.M == len(inside) and db2.info == 0
                 kl_b, ku_b, nbytes_b, _blk = eng.band_plan()
+                plan_flops = eng.direct_plan_flops()
                 bres = np.linalg.norm(A @ db.q - (B @ db.q) * db.lambda_, axis=0) / np.maximum(np.abs(db.lambda_), 1.0) if okb else [float("nan")]
                 def split(r, total_s, plan_s=0.0):
                     ph = r.stats.get("phase_seconds", {})
@@ -518,12 +519,16 @@ def main():
                     "value": round(db.M / dtb, 3) if okb else 0.0, "unit": "eigenpairs/s", "ms_per_call": round(1e3 * dtb, 2),
                     "ms_cached_factors": round(1e3 * dtb2, 2), "loops": int(db.loop), "factorizations": int(db.stats.get("factorizations", 0)),
                     "split_ms_first_call": split(db, dtb, dt_plan), "split_ms_cached": split(db2, dtb2),
-                    "split_note": "plan = pattern scan + reverse Cuthill-McKee (host); sweeps_wall - sweeps_gpu = allocation of the factor "
-                                  "slots (16 x GB_per_node, hipMalloc) and host staging; other = start subspace, eigenvector download, host checks",
-
+                    "split_note": "plan = pattern scan + reverse Cuthill-McKee + nested dissection / fronts / maps (host); sweeps_wall - sweeps_gpu "
+                                  "= allocation of the factor slots (16 x GB_per_node, hipMalloc) and host staging; other = start subspace, "
+                                  "eigenvector download, host checks",
+                    "plan": {2: "multifrontal LU on a nested-dissection tree (batched dense fronts)", 1: "blocked band LU after reverse Cuthill-McKee",
+                             0: "narrow band LU"}.get(int(_blk), "?"),
+                    "flop_per_node": plan_flops, "band_flop_per_node": 8.0 * A.shape[0] * kl_b * (kl_b + ku_b),
                     "band": [int(kl_b), int(ku_b)], "GB_per_node": round(nbytes_b / 1e9, 3), "max_residual": float(np.max(bres)),
-                    "note": "same solve with solver='banded': band LU of z B - A per node after reverse Cuthill-McKee (the reference's default is "
-                            "a sparse LU per node); ms_per_call factors all nodes, ms_cached_factors repeats the call on the cached factors"}
+                    "note": "same solve with solver='banded', the library's sparse DIRECT solver: one LU of z B - A per node (the reference's "
+                            "default for sparse input is a sparse LU per node, UMFPACK); ms_per_call factors all nodes, ms_cached_factors "
+                            "repeats the call on the cached factors; `band` is the band the band LU would eliminate (FH_MF=0)"}
                 eng.set_solver("cocg")
                 eng.free_factors()
             except Exception as exc:

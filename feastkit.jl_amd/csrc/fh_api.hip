@@ -357,6 +357,11 @@ extern "C" int feasthip_release_factors(feasthip_handle h) {
     for (void* p : h->band_factors) if (p) hipFree(p);
     for (int* p : h->band_pivots) if (p) hipFree(p);
     h->band_factors.clear(); h->band_pivots.clear(); h->band_valid.clear(); h->band_z.clear();
+    // the multifrontal solver's transient buffers (work arena, substitution panels: together more than the factors themselves)
+    for (const char* name : {"mf_work", "mf_y", "mf_z", "mf_ptrs", "mf_info"}) {
+        auto it = h->bufs.find(name);
+        if (it != h->bufs.end()) { hipFree(it->second.first); h->bufs.erase(it); }
+    }
     return 0;
 }
 

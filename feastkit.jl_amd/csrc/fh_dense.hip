@@ -859,12 +859,12 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, i
 // LAPACK hold at their tolerances -- which is the guarantee ZGEMM3M gives.  FH_LU_3M=0 selects the four-product form.
 template <int KC, typename T, bool M3>
 __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm_direct(T* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
-                                                              int c1, int TR, int TC) {
+                                                              int c1, int TR, int TC, int compact = 0) {
     T* A = LUs[blockIdx.y];
     __shared__ T Us[KC][64];
     const int t = threadIdx.x;
     int tr, tc;
-    if (gridDim.x == (unsigned)(TR * TC)) {     // compact grid (small products in large batches: the multifrontal fronts) -- no idle workgroups
+    if (compact) {                              // compact grid (small products in large batches: the multifrontal fronts) -- no idle workgroups
         tr = blockIdx.x % TR; tc = blockIdx.x / TR;
     } else {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -1587,8 +1587,8 @@ static int lu_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const
         if (staged || sizeof(T) != sizeof(cplx)) hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
         else {
             static const bool m3_off = getenv("FH_LU_3M") && atoi(getenv("FH_LU_3M")) == 0;
-            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
-            else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC);
+            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC, 0);
+            else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dlus, N, k0, kd, r0, r1, c0, c1, TR, TC, 0);
         }
         fh_prof_end(h);
     };
@@ -2024,8 +2024,8 @@ static int wband_factor_t(feasthip_ctx* h, int nf, void* const* abs_host, T** db
         const int nsuper = ((TR + 7) / 8) * ((TC + sw - 1) / sw);
         const dim3 grid(((nsuper + 7) / 8) * 8 * 8 * sw, nf);
         if constexpr (sizeof(T) != sizeof(cplx)) hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
-        else if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
-        else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC);
+        else if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC, 0);
+        else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, dbases, lda, k0, kd, r0, r1, c0, c1, TR, TC, 0);
     };
     // Look-ahead, as in the dense factorisation: the panels of a block column run one workgroup per node, so the update right
     // of block column b is split by columns -- the NEXT block column [Kend, Kend + WB) on the main stream, the REST
@@ -2201,12 +2201,69 @@ struct fh_mf_state {
     std::vector<size_t> slot_off;          // group -> first entry of d_slots
     std::vector<size_t> kid_off[2];        // group, side -> first entry of d_kids
     double band_flops = 0.0;
+    // the groups of one tree height are independent: with FH_MF_STREAMS=2..4 they run side by side on that many streams (the
+    // mid-height groups are 16 - 80 matrices whose panel chains leave most of the chip idle); default: one stream, see fh_mf_make_plan
+    hipStream_t extra[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int nextra = 0;
 };
+
+// runs body(g) for every group, level by level (ascending or descending heights), the groups of a level round-robin over the
+// main stream and the extra streams; h->stream is switched for the duration of a group (launch helpers and profiler follow it)
+template <typename Body>
+static int mf_for_levels(feasthip_ctx* h, fh_mf_state* S, bool ascending, Body body) {
+    const fh_mf::plan& P = S->P;
+    const int ng = (int)P.groups.size();
+    std::vector<std::pair<int, int>> levels;
+    for (int g = 0; g < ng;) {
+        int e = g;
+        while (e + 1 < ng && P.groups[e + 1].height == P.groups[g].height) ++e;
+        levels.push_back({g, e});
+        g = e + 1;
+    }
+    if (!ascending) std::reverse(levels.begin(), levels.end());
+    const hipStream_t main_s = h->stream;
+    int rc = 0;
+    for (const auto& lv : levels) {
+        const int cnt = lv.second - lv.first + 1;
+        const int ns = std::min(cnt, 1 + S->nextra);
+        if (ns > 1) {
+            if (hipEventRecord(S->ev_fork, main_s) != hipSuccess) { h->last_error = "hipEventRecord(multifrontal)"; return FEASTHIP_ERROR_INTERNAL; }
+            for (int q = 1; q < ns; ++q)
+                if (hipStreamWaitEvent(S->extra[q - 1], S->ev_fork, 0) != hipSuccess) { h->last_error = "hipStreamWaitEvent(multifrontal)"; return FEASTHIP_ERROR_INTERNAL; }
+        }
+        // the largest groups first, one after the other on the streams in turn
+        std::vector<int> order(cnt);
+        for (int q = 0; q < cnt; ++q) order[q] = lv.first + q;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return P.groups[a].flops > P.groups[b].flops; });
+        for (int q = 0; q < cnt && !rc; ++q) {
+            const int st = q % ns;
+            h->stream = st == 0 ? main_s : S->extra[st - 1];
+            rc = body(order[q]);
+        }
+        h->stream = main_s;
+        if (ns > 1) {
+            for (int q = 1; q < ns; ++q) {
+                if (hipEventRecord(S->ev_join[q - 1], S->extra[q - 1]) != hipSuccess || hipStreamWaitEvent(main_s, S->ev_join[q - 1], 0) != hipSuccess) {
+                    h->last_error = "hipEventRecord(multifrontal join)";
+                    return FEASTHIP_ERROR_INTERNAL;
+                }
+            }
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
 
 void fh_mf_free(feasthip_ctx* h) {
     fh_mf_state* S = (fh_mf_state*)h->mf;
     if (!S) return;
     for (void* p : {(void*)S->d_asm_dst, (void*)S->d_asm_src, (void*)S->d_rel, (void*)S->d_perm, (void*)S->d_kids, (void*)S->d_slots}) if (p) (void)hipFree(p);
+    for (int q = 0; q < 3; ++q) {
+        if (S->extra[q]) { (void)hipStreamSynchronize(S->extra[q]); (void)hipStreamDestroy(S->extra[q]); }
+        if (S->ev_join[q]) (void)hipEventDestroy(S->ev_join[q]);
+    }
+    if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
     delete S;
     h->mf = nullptr;
 }
@@ -2264,6 +2321,19 @@ int fh_mf_make_plan(feasthip_ctx* h, int leaf) {
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
     };
     h->mf = S;
+    {
+        // default ONE stream.  Measured on cfg 3 with four: factorisation 110 -> 101 ms, sweep 24.7 -> 23.6 ms -- and the dense
+        // LU on the same handle fell from 0.069 to 0.104 s per cfg-2 solve: with four streams of the handle in use the CU-masked
+        // side stream of the LU look-ahead no longer gets a hardware queue of its own and serialises with the main stream.
+        const int want = getenv("FH_MF_STREAMS") ? std::max(1, std::min(4, atoi(getenv("FH_MF_STREAMS")))) : 1;
+        bool ok = hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int q = 0; q + 1 < want && ok; ++q) {
+            ok = hipStreamCreateWithFlags(&S->extra[q], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&S->ev_join[q], hipEventDisableTiming) == hipSuccess;
+            if (ok) S->nextra = q + 1;
+        }
+        if (!ok) (void)hipGetLastError();          // fewer streams (or none): the levels run in order on the main stream
+    }
     if (!up(P.asm_dst.data(), P.asm_dst.size() * sizeof(int), (void**)&S->d_asm_dst) || !up(P.asm_src.data(), P.asm_src.size() * sizeof(int), (void**)&S->d_asm_src) ||
         !up(P.rel.data(), P.rel.size() * sizeof(int), (void**)&S->d_rel) || !up(P.perm.data(), P.perm.size() * sizeof(int), (void**)&S->d_perm) ||
         !up(kids.data(), kids.size() * sizeof(mf_kid), (void**)&S->d_kids) || !up(slots.data(), slots.size() * sizeof(mf_slot), (void**)&S->d_slots)) {
@@ -2483,7 +2553,7 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
     FH_CHECK(hipMemsetAsync(dinfo, 0, tot * sizeof(int), h->stream));
     static const bool m3_off = getenv("FH_LU_3M") && atoi(getenv("FH_LU_3M")) == 0;
     const bool bid = h->csr.b_identity != 0, cz = h->csr.is_complex != 0;
-    for (int g = 0; g < ng; ++g) {
+    auto factor_group = [&](int g) -> int {
         const fh_mf::group& G = P.groups[g];
         const int F = (int)G.fronts.size(), nmat = F * nf, n = G.n, np = G.np, nb = G.nb;
         T** W = ptr.work + ptr.off[g];
@@ -2540,9 +2610,10 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
             const int full = ((nsuper + 7) / 8) * 8 * 8 * sw;
             // the XCD-aware super-tile order pays on long trailing updates; on a 3 x 3 tile product of 12 000 fronts its idle
             // workgroups were 95 % of the launch (51 ms for one k = 32 update of the leaf group)
-            const dim3 grid(nmat > 64 || 2 * TR * TC <= full ? TR * TC : full, nmat);
-            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC);
-            else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC);
+            const int compact = (nmat > 64 || 2 * TR * TC <= full) ? 1 : 0;
+            const dim3 grid(compact ? TR * TC : full, nmat);
+            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC, compact);
+            else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC, compact);
         };
         int* ginfo = dinfo + ptr.off[g];
         for (int K0 = 0; K0 < np; K0 += SOLVE_KB) {
@@ -2586,7 +2657,9 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
         }
         hipLaunchKernelGGL(k_build_perm, dim3(nmat), dim3(FH_BLOCK), (size_t)np * sizeof(int), h->stream, PV, np);
         fh_prof_end(h);
-    }
+        return 0;
+    };
+    if ((rc = mf_for_levels(h, S, true, factor_group))) return rc;
     std::vector<int> hinfo(tot);
     FH_CHECK(hipMemcpyAsync(hinfo.data(), dinfo, tot * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
@@ -2623,7 +2696,7 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
             else hipLaunchKernelGGL((k_solve_diag<LD, false, false, T>), grid, block, 0, h->stream, ST, IN, OUTp, stride, gd, K0, kb);
         }
     };
-    for (int g = 0; g < ng; ++g) {                               // forward: leaves first
+    auto forward_group = [&](int g) -> int {                     // forward: leaves first
         const fh_mf::group& G = P.groups[g];
         const int F = (int)G.fronts.size(), nmat = F * nf, n = G.n, np = G.np;
         T* Yg = Y + G.rhs_off * (size_t)nf * LD;
@@ -2653,8 +2726,9 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
             if (r0 < n)
                 hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((n - r0 + 63) / 64, nmat), dim3(FH_BLOCK), 0, h->stream, ST, Yg, Zg, stride, gu, K0, LU_NB * kb, r0, n, cta);
         }
-    }
-    for (int g = ng - 1; g >= 0; --g) {                          // backward: root first
+        return 0;
+    };
+    auto backward_group = [&](int g) -> int {                    // backward: root first
         const fh_mf::group& G = P.groups[g];
         const int F = (int)G.fronts.size(), nmat = F * nf, n = G.n, np = G.np, nb = G.nb;
         T* Yg = Y + G.rhs_off * (size_t)nf * LD;
@@ -2679,7 +2753,10 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
         }
         hipLaunchKernelGGL((k_mf_scatter<LD>), dim3(mf_blocks((size_t)np * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F, Yg,
                            S->d_perm, OUT, out_stride, n);
-    }
+        return 0;
+    };
+    if ((rc = mf_for_levels(h, S, true, forward_group))) return rc;
+    if ((rc = mf_for_levels(h, S, false, backward_group))) return rc;
     fh_prof_end(h);
     return 0;
 }

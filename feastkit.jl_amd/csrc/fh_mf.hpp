@@ -315,11 +315,21 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
     // ---- storage offsets.  Work arena: a group's fronts live from its assembly to the assembly of the last parent group;
     // first-fit placement over those lifetimes (groups are processed in index order).
     {
+        // (the groups of one height may run side by side on several streams: a region is taken when its LEVEL starts and
+        //  given back when the level of its last parent group has ended)
         const int ng = (int)P.groups.size();
+        std::vector<int> lev_first(ng), lev_last(ng);
+        for (int g = 0; g < ng;) {
+            int e = g;
+            while (e + 1 < ng && P.groups[e + 1].height == P.groups[g].height) ++e;
+            for (int q = g; q <= e; ++q) { lev_first[q] = g; lev_last[q] = e; }
+            g = e + 1;
+        }
         std::vector<int> last_use(ng);
         for (int g = 0; g < ng; ++g) {
             last_use[g] = g;
             for (int f : P.groups[g].fronts) { const int p = P.fronts[f].parent; if (p >= 0) last_use[g] = std::max(last_use[g], P.fronts[p].group); }
+            last_use[g] = lev_last[last_use[g]];
         }
         struct placed { size_t off, len; int last; };
         std::vector<placed> live;
@@ -327,7 +337,7 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
             group& G = P.groups[g];
             G.work_per = (size_t)G.n * G.n + inv32_elems(G.np);
             const size_t len = G.work_per * G.fronts.size();
-            live.erase(std::remove_if(live.begin(), live.end(), [&](const placed& p) { return p.last < g; }), live.end());
+            live.erase(std::remove_if(live.begin(), live.end(), [&](const placed& p) { return p.last < lev_first[g]; }), live.end());
             std::sort(live.begin(), live.end(), [](const placed& a, const placed& c) { return a.off < c.off; });
             size_t off = 0;
             for (const placed& p : live) { if (off + len <= p.off) break; off = std::max(off, p.off + p.len); }

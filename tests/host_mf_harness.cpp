@@ -93,6 +93,31 @@ static int check_plan(const csr& M, const fh_mf::plan& P) {
         for (int c : F.child) if (c >= 0 && (P.fronts[c].parent != (int)f || c >= (int)f)) return fail("child", (int)f);
     }
     if ((int)piv != N) return fail("pivot count", (int)piv);
+    {   // work arena: regions whose lifetimes overlap must not (a group lives from the start of its level -- the groups of a
+        // level may run side by side -- to the end of the level of its last parent group)
+        const int ng = (int)P.groups.size();
+        std::vector<int> first(ng), last(ng);
+        for (int g = 0; g < ng; ++g) {
+            int a = g, b = g;
+            while (a > 0 && P.groups[a - 1].height == P.groups[g].height) --a;
+            while (b + 1 < ng && P.groups[b + 1].height == P.groups[g].height) ++b;
+            first[g] = a; last[g] = b;
+        }
+        std::vector<int> until(ng);
+        for (int g = 0; g < ng; ++g) {
+            int u = g;
+            for (int f : P.groups[g].fronts) if (P.fronts[f].parent >= 0) u = std::max(u, P.fronts[P.fronts[f].parent].group);
+            until[g] = last[u];
+        }
+        for (int a = 0; a < ng; ++a)
+            for (int b = a + 1; b < ng; ++b) {
+                if (first[b] > until[a]) continue;                      // b's level starts after a was given back
+                const size_t a0 = P.groups[a].work_off, a1 = a0 + P.groups[a].work_per * P.groups[a].fronts.size();
+                const size_t b0 = P.groups[b].work_off, b1 = b0 + P.groups[b].work_per * P.groups[b].fronts.size();
+                if (a0 < b1 && b0 < a1) return fail("arena overlap", a * 1000 + b);
+                if (a1 > P.work_elems || b1 > P.work_elems) return fail("arena size", a);
+            }
+    }
     // every CSR entry assembled exactly once; identity diagonals exactly once
     std::vector<int> hits(M.col.size(), 0);
     int diag = 0;
