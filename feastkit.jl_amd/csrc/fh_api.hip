@@ -116,7 +116,7 @@ void fh_prof_collect(feasthip_ctx* h) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             fh_prof_class& pc = h->prof[ep.cls + std::string("#sampled")];
-            pc.total_ms += std::max(0.0, (double)ms - std::max(0.0, h->prof_overhead_ms));
+            pc.total_ms += ms;
             pc.launches += 1;
         }
         if (h->event_pool.size() < 8192) { h->event_pool.push_back(ep.a); h->event_pool.push_back(ep.b); }
@@ -3104,39 +3104,10 @@ extern "C" int feasthip_last_column_iterations(feasthip_handle h, int* out, int 
     return 0;
 }
 
-// What an event bracket measures beyond the kernel it brackets -- the dispatch gap after the previous command and the two
-// timestamp writes -- calibrated once per handle on an empty kernel in a busy queue (the smallest of 24 brackets) and taken off
-// every sample: rocprofv3's kernel trace reports the kernel alone, and with thousands of 4-us launches of converged nodes in a
-// class the brackets read 7 % above it (k_fused_vec: 155.7 against 145.1 us under the same run) before this correction.
-__global__ void k_prof_null() {}
-static void fh_prof_calibrate(feasthip_ctx* h) {
-    if (h->prof_overhead_ms >= 0.0) return;
-    h->prof_overhead_ms = 0.0;
-    if (getenv("FH_PROF_RAW")) return;
-    const int n = 24;
-    hipEvent_t ev[2 * n];
-    int made = 0;
-    for (; made < 2 * n; ++made) if (hipEventCreate(&ev[made]) != hipSuccess) break;
-    if (made == 2 * n) {
-        for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(k_prof_null, dim3(1), dim3(64), 0, h->stream);
-        for (int q = 0; q < n; ++q) {
-            hipEventRecord(ev[2 * q], h->stream);
-            hipLaunchKernelGGL(k_prof_null, dim3(1), dim3(64), 0, h->stream);
-            hipEventRecord(ev[2 * q + 1], h->stream);
-        }
-        if (hipStreamSynchronize(h->stream) == hipSuccess) {
-            float best = 1e30f;
-            for (int q = 0; q < n; ++q) { float ms = 0.f; if (hipEventElapsedTime(&ms, ev[2 * q], ev[2 * q + 1]) == hipSuccess && ms > 0.f) best = std::min(best, ms); }
-            if (best < 0.05f) h->prof_overhead_ms = best;           // (anything larger is not a dispatch gap: leave the samples alone)
-        }
-    }
-    for (int q = 0; q < made; ++q) hipEventDestroy(ev[q]);
-    (void)hipGetLastError();
-}
 extern "C" int feasthip_profile_enable(feasthip_handle h, int enable) {
     if (!h) return FEASTHIP_ERROR_INTERNAL;
     h->profiling = enable ? 1 : 0;
-    if (enable) { fh_prof_calibrate(h); h->prof_host_s = 0.0; h->prof_t0 = fh_now_s(); }
+    if (enable) { h->prof_host_s = 0.0; h->prof_t0 = fh_now_s(); }
     return 0;
 }
 extern "C" int feasthip_profile_reset(feasthip_handle h) {

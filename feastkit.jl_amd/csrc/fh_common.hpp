@@ -226,7 +226,6 @@ struct feasthip_ctx {
     int prof_mult = 1;                          // sampling period multiplier, raised when the host cost of sampling shows
     double prof_host_s = 0.0;                   // host seconds spent recording / reading events since profile_enable
     double prof_t0 = 0.0;                       // steady-clock seconds at profile_enable
-    double prof_overhead_ms = -1.0;             // event-bracket overhead (dispatch gap + timestamps), calibrated at the first profile_enable; FH_PROF_RAW: none
 };
 
 // workspace helper: returns a device buffer of at least `bytes`, reallocating if needed
