@@ -10,6 +10,7 @@
 // right-hand sides / solutions are row-major N x ld panels (fh_common.hpp), so a row
 // interchange moves one contiguous line and the triangular sweeps stream whole rows.
 #include <stdlib.h>
+#include <chrono>
 #include "fh_common.hpp"
 #include "fh_kernels.hpp"
 #include "fh_dense.hpp"
@@ -2541,10 +2542,15 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
     const int ng = (int)P.groups.size();
     void* p;
     int rc;
+    const bool dbg = getenv("FH_DEBUG_TIMING") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count(); };
     if ((rc = fh_get_buf(h, "mf_work", (size_t)nf * P.work_elems * sizeof(T), &p))) return rc;
     T* work = (T*)p;
+    const double t_work = since();
     mf_ptrs ptr;
     if ((rc = mf_pointer_arrays(h, *S, nf, stores, pivs, work, true, ptr))) return rc;
+    const double t_ptrs = since();
     const size_t tot = ptr.off[ng];
     for (int g = 0; g < ng; ++g)
         if (P.groups[g].fronts.size() * (size_t)nf > 65535) { h->last_error = "multifrontal LU: more than 65535 fronts x nodes in one group"; return FEASTHIP_ERROR_FPM; }
@@ -2660,9 +2666,12 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
         return 0;
     };
     if ((rc = mf_for_levels(h, S, true, factor_group))) return rc;
+    const double t_launch = since();
     std::vector<int> hinfo(tot);
     FH_CHECK(hipMemcpyAsync(hinfo.data(), dinfo, tot * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FH_CHECK(hipStreamSynchronize(h->stream));
+    if (dbg) fprintf(stderr, "[feasthip] multifrontal LU: work arena %.1f ms, pointer arrays %.1f ms, launches %.1f ms, drained at %.1f ms\n", t_work, t_ptrs - t_work,
+                     t_launch - t_ptrs, since());
     info_out.assign(nf, 0);
     for (int g = 0; g < ng; ++g) {
         const size_t F = P.groups[g].fronts.size();
@@ -2767,7 +2776,10 @@ int fh_mf_solve(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, 
     if (!S) { h->last_error = "multifrontal LU: no plan"; return FEASTHIP_ERROR_INTERNAL; }
     mf_ptrs ptr;
     int rc;
+    const auto t_in = std::chrono::steady_clock::now();
     if ((rc = mf_pointer_arrays(h, *S, nf, stores, pivs, nullptr, false, ptr))) return rc;
+    struct report { std::chrono::steady_clock::time_point t0, t1; ~report() { if (getenv("FH_DEBUG_TIMING")) fprintf(stderr, "[feasthip] multifrontal solve: pointer arrays %.1f ms, buffers + launches %.1f ms (host)\n",
+        std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count()); } } rep{t_in, std::chrono::steady_clock::now()};
     if (ld == 16) return mf_solve_ld<16>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
     if (ld == 32) return mf_solve_ld<32>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
     return mf_solve_ld<64>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);

@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -71,6 +72,7 @@ struct plan {
 };
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline double plan_store_slack() { const char* e = getenv("FH_MF_STORE_SLACK"); const double v = e ? atof(e) : 0.0; return v >= 1.0 ? v : 1.25; }
 static inline size_t inv32_elems(int np) { return (size_t)(np / 32) * 2 * 32 * 32; }
 static inline size_t inv128_elems(int np) { return (size_t)((np + 127) / 128) * 2 * 128 * 128; }
 
@@ -271,9 +273,12 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
         for (int f = 0; f < nf; ++f) byh[P.fronts[f].height].push_back(f);
         for (int hgt = 0; hgt <= maxh; ++hgt) {
             std::vector<int>& fs = byh[hgt];
+            // by pivot class (the padded pivot count sets the panel steps AND pads both factor blocks), then by boundary size
             std::sort(fs.begin(), fs.end(), [&](int a, int c) {
-                const int na = P.fronts[a].npiv + P.fronts[a].nbnd, nc = P.fronts[c].npiv + P.fronts[c].nbnd;
-                return na != nc ? na > nc : a < c;
+                const int pa = round_up(P.fronts[a].npiv, 32), pc = round_up(P.fronts[c].npiv, 32);
+                if (pa != pc) return pa > pc;
+                if (P.fronts[a].nbnd != P.fronts[c].nbnd) return P.fronts[a].nbnd > P.fronts[c].nbnd;
+                return a < c;
             });
             size_t i = 0;
             while (i < fs.size()) {
@@ -285,8 +290,12 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
                 // A group costs (panel steps) x (latency of one step: a chain of small launches, ~0.2 ms whatever the batch)
                 // + (padded flops) / (MFMA rate); in flops per quadrature node one step is worth about step_flops.  A front
                 // joins while that is cheaper than a group of its own.
+                // The factor store keeps a group's padded geometry, so a second rule bounds the memory: a front does not join
+                // when the group's padded store would exceed store_slack x what its members need on their own.
                 const double step_flops = 2.5e8;
-                double cost = 0.0;
+                const double store_slack = plan_store_slack();
+                auto store_of = [](int np_, int nb_) { return (double)(np_ + nb_) * np_ + 64.0 * np_ + (double)np_ * nb_; };
+                double cost = 0.0, own_store = 0.0;
                 for (; j < fs.size(); ++j) {
                     const front& F = P.fronts[fs[j]];
                     const int np2 = round_up(std::max(npm, F.npiv), 32), nb2 = round_up(std::max(nbm, F.nbnd), 16);
@@ -294,9 +303,11 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
                     const int np1 = round_up(F.npiv, 32), nb1 = round_up(F.nbnd, 16);
                     const double alone = (np1 / 32) * step_flops + partial_lu_flops(np1 + nb1, np1);
                     if (j > i && merged > cost + alone) break;
+                    if (j > i && (double)(j - i + 1) * store_of(np2, nb2) > store_slack * (own_store + store_of(np1, nb1))) break;
                     if (j - i >= 2048) break;                    // (fronts x quadrature nodes is a grid dimension)
                     npm = std::max(npm, F.npiv); nbm = std::max(nbm, F.nbnd);
                     exact += partial_lu_flops(F.npiv + F.nbnd, F.npiv);
+                    own_store += store_of(np1, nb1);
                     cost = merged;
                 }
                 G.np = round_up(npm, 32); G.nb = round_up(nbm, 16); G.n = G.np + G.nb;
