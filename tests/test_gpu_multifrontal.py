@@ -132,3 +132,45 @@ def test_cfg3_takes_the_multifrontal_plan(engine):
     X = r.q[:, :r.M]
     res = np.linalg.norm(A @ X - (B @ X) * r.lambda_[:r.M], axis=0) / np.linalg.norm(X, axis=0)
     assert res.max() < 1e-10
+
+
+def test_multifrontal_fuzz(engine, force_mf):
+    """Seeded random cases through the multifrontal solver -- grids with random holes (irregular separators), random band
+    graphs, disconnected unions; size, leaf size, right-hand sides, value type, B present or not -- every case against SuperLU."""
+    import os
+    rng = np.random.default_rng(20261005)
+    for case in range(14):
+        kind = int(rng.integers(0, 3))
+        cplx = bool(rng.integers(0, 2))
+        m = int(rng.integers(1, 65))
+        os.environ["FH_MF_LEAF"] = str(int(rng.choice([8, 16, 32, 64, 128])))
+        try:
+            if kind == 0:                                            # grid with holes
+                shape = (int(rng.integers(4, 22)), int(rng.integers(4, 18)), int(rng.integers(1, 9)))
+                A, B = grid_pencil(*shape, seed=500 + case, cplx=cplx, unsym=bool(rng.integers(0, 2)))
+                n = A.shape[0]
+                keep = np.sort(rng.choice(n, size=max(40, int(n * rng.uniform(0.6, 1.0))), replace=False))
+                A, B = A[keep][:, keep].tocsr(), B[keep][:, keep].tocsr()
+                desc = f"grid {shape} keep {len(keep)}"
+            elif kind == 1:                                          # random band graph
+                n = int(rng.integers(140, 2600))
+                band = int(rng.integers(3, min(200, n // 3)))
+                A, B = random_pencil(n, band, float(rng.uniform(0.02, 0.5)) * min(1.0, 30.0 / band), 900 + case, cplx, bool(rng.integers(0, 2)))
+                desc = f"band n={n} band={band}"
+            else:                                                    # two unconnected blocks
+                A1, B1 = grid_pencil(int(rng.integers(3, 12)), int(rng.integers(3, 12)), int(rng.integers(1, 6)), seed=700 + case, cplx=cplx)
+                A2, B2 = random_pencil(int(rng.integers(50, 600)), 12, 0.3, 800 + case, cplx, True)
+                A, B = sp.block_diag([A1, A2], format="csr"), sp.block_diag([B1, B2], format="csr")
+                desc = f"blocks {A1.shape[0]} + {A2.shape[0]}"
+            if rng.integers(0, 3) == 0:
+                B = None
+            engine.set_problem(A, B)
+            engine.set_solver("banded")
+            assert engine.band_plan()[3] == 2
+            z = complex(rng.uniform(-0.5, 0.5), rng.uniform(0.05, 1.0))
+            try:
+                check_solve(engine, A, B, z, m, seed=case)
+            except AssertionError as exc:
+                raise AssertionError(f"case {case}: {desc} m={m} cplx={cplx} leaf={os.environ['FH_MF_LEAF']} B={'I' if B is None else 'tri'}: {exc}")
+        finally:
+            del os.environ["FH_MF_LEAF"]

@@ -44,6 +44,13 @@ fpm = fk.feastinit(); fpm[2] = 8
 d = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 32, fpm, solver="banded")
 out += [d.info, d.M, d.epsout, d.stats.get("factorizations", -1)] + list(np.sort(d.lambda_))
 eng.close()
+# the same through the multifrontal plan of the sparse direct solver
+del os.environ["FH_WBAND"]
+os.environ["FH_MF"] = "1"
+eng = fk.HipEngine(0)
+d = fk.feast_hip_hermitian(eng, A, B, 0.0, 0.42, 32, fpm, solver="banded")
+out += [d.info, d.M, d.epsout, d.stats.get("factorizations", -1), eng.band_plan()[3]] + list(np.sort(d.lambda_))
+eng.close()
 np.save(r"{out}/g%d.npy" % rank, np.array(out, dtype=float))
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -76,6 +83,9 @@ def test_two_ranks_one_gpu_match_single_rank(engine, tmp_path):
     off += 5
     assert (int(g0[off]), int(g0[off + 1])) == (0, n) and g0[off + 2] <= 1e-12 and int(g0[off + 3]) == 4     # 4 of the 8 nodes factored per rank
     assert np.allclose(g0[off + 4: off + 4 + n], inside, atol=1e-10)
+    off += 4 + n                                                          # multifrontal plan: same result, 4 factorisations per rank
+    assert (int(g0[off]), int(g0[off + 1])) == (0, n) and g0[off + 2] <= 1e-12 and int(g0[off + 3]) == 4 and int(g0[off + 4]) == 2
+    assert np.allclose(g0[off + 5: off + 5 + n], inside, atol=1e-10)
 
 
 WORKER4 = r'''
