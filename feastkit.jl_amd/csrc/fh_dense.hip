@@ -2225,13 +2225,22 @@ static int mf_for_levels(feasthip_ctx* h, fh_mf_state* S, bool ascending, Body b
     if (!ascending) std::reverse(levels.begin(), levels.end());
     const hipStream_t main_s = h->stream;
     int rc = 0;
+    // Default: the handle's OWN second stream -- the CU-masked side stream of the LU look-ahead (no further hardware queue) --
+    // takes every second group of a level.  FH_MF_SIDE=0: strictly one stream.
+    hipStream_t extra[3] = {S->extra[0], S->extra[1], S->extra[2]};
+    hipEvent_t ev_fork = S->ev_fork, ev_join[3] = {S->ev_join[0], S->ev_join[1], S->ev_join[2]};
+    int nextra = S->nextra;
+    static const bool side_off = getenv("FH_MF_SIDE") && atoi(getenv("FH_MF_SIDE")) == 0;
+    if (nextra == 0 && !side_off && h->lu_lookahead != 0 && lu_side_stream(h, lu_lookahead_reserve(16)) && h->side_stream && h->lu_ev_next && h->lu_ev_rest) {
+        extra[0] = h->side_stream; ev_fork = h->lu_ev_next; ev_join[0] = h->lu_ev_rest; nextra = 1;
+    }
     for (const auto& lv : levels) {
         const int cnt = lv.second - lv.first + 1;
-        const int ns = std::min(cnt, 1 + S->nextra);
+        const int ns = std::min(cnt, 1 + nextra);
         if (ns > 1) {
-            if (hipEventRecord(S->ev_fork, main_s) != hipSuccess) { h->last_error = "hipEventRecord(multifrontal)"; return FEASTHIP_ERROR_INTERNAL; }
+            if (hipEventRecord(ev_fork, main_s) != hipSuccess) { h->last_error = "hipEventRecord(multifrontal)"; return FEASTHIP_ERROR_INTERNAL; }
             for (int q = 1; q < ns; ++q)
-                if (hipStreamWaitEvent(S->extra[q - 1], S->ev_fork, 0) != hipSuccess) { h->last_error = "hipStreamWaitEvent(multifrontal)"; return FEASTHIP_ERROR_INTERNAL; }
+                if (hipStreamWaitEvent(extra[q - 1], ev_fork, 0) != hipSuccess) { h->last_error = "hipStreamWaitEvent(multifrontal)"; return FEASTHIP_ERROR_INTERNAL; }
         }
         // the largest groups first, one after the other on the streams in turn
         std::vector<int> order(cnt);
@@ -2239,13 +2248,13 @@ static int mf_for_levels(feasthip_ctx* h, fh_mf_state* S, bool ascending, Body b
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return P.groups[a].flops > P.groups[b].flops; });
         for (int q = 0; q < cnt && !rc; ++q) {
             const int st = q % ns;
-            h->stream = st == 0 ? main_s : S->extra[st - 1];
+            h->stream = st == 0 ? main_s : extra[st - 1];
             rc = body(order[q]);
         }
         h->stream = main_s;
         if (ns > 1) {
             for (int q = 1; q < ns; ++q) {
-                if (hipEventRecord(S->ev_join[q - 1], S->extra[q - 1]) != hipSuccess || hipStreamWaitEvent(main_s, S->ev_join[q - 1], 0) != hipSuccess) {
+                if (hipEventRecord(ev_join[q - 1], extra[q - 1]) != hipSuccess || hipStreamWaitEvent(main_s, ev_join[q - 1], 0) != hipSuccess) {
                     h->last_error = "hipEventRecord(multifrontal join)";
                     return FEASTHIP_ERROR_INTERNAL;
                 }
