@@ -217,11 +217,11 @@ static int band_make_plan(feasthip_ctx* h) {
     }
     // Multifrontal plan (fh_mf.hpp, numeric phase in fh_dense.hip): fill confined to the fronts of a nested-dissection tree
     // instead of the band.  Taken when its (padded) work is under half the band elimination's -- the band LU streams one
-    // long trailing update per block column, the fronts are many smaller batches -- complex128 factors only.
+    // long trailing update per block column, the fronts are many smaller batches.
     // FH_MF=0 never, FH_MF=1 always (tests); FH_MF_LEAF: largest leaf subset (default 64).
     {
         const int mode = mf_mode;
-        if (mode != 0 && !(force_wide && mode != 1) && h->factor_precision != 32 && (N >= 2048 || mode == 1)) {
+        if (mode != 0 && !(force_wide && mode != 1) && (N >= 2048 || mode == 1)) {
             const int leaf = getenv("FH_MF_LEAF") ? std::max(8, atoi(getenv("FH_MF_LEAF"))) : 64;
             const auto t0 = std::chrono::steady_clock::now();
             if (fh_mf_make_plan(h, leaf) == 0) {
@@ -231,7 +231,7 @@ static int band_make_plan(feasthip_ctx* h) {
                 if (getenv("FH_DEBUG_TIMING"))
                     fprintf(stderr, "[feasthip] multifrontal plan (%.1f ms): %.3e flop and %.2f GB per node, band %.3e flop and %.2f GB -> %s\n",
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), fh_mf_plan_flops(h),
-                            fh_mf_store_bytes(h) / 1e9, band_flops, (double)fh_wband_elems((int)N, kl1, ku1) * sizeof(cplx) / 1e9, take ? "multifrontal" : "band");
+                            fh_mf_store_bytes(h, 64) / 1e9, band_flops, (double)fh_wband_elems((int)N, kl1, ku1) * sizeof(cplx) / 1e9, take ? "multifrontal" : "band");
                 if (take) { h->band_plan = 3; h->band_kl = kl1; h->band_ku = ku1; return 0; }
                 fh_mf_free(h);
             } else {
@@ -252,7 +252,7 @@ static int band_make_plan(feasthip_ctx* h) {
 
 static size_t band_slot_bytes(feasthip_ctx* h) {
     const size_t N = (size_t)h->csr.N;
-    if (h->band_plan == 3) return fh_mf_store_bytes(h);
+    if (h->band_plan == 3) return fh_mf_store_bytes(h, h->band_prec);
     if (h->band_plan == 2) return fh_wband_elems((int)N, h->band_kl, h->band_ku) * (h->band_prec == 32 ? sizeof(cplxf) : sizeof(cplx));
     return ((size_t)2 * h->band_kl + h->band_ku + 1) * N * sizeof(cplx);
 }
@@ -273,7 +273,7 @@ static int band_check(feasthip_ctx* h) {
 static int band_ensure_slots(feasthip_ctx* h, int nslots) {
     const size_t N = (size_t)h->csr.N;
     // complex64 factors (feasthip_set_solver factor_precision = 32) exist for the blocked plan only; the caller refines in fp64
-    const int prec = (h->band_plan == 2 && h->factor_precision == 32) ? 32 : 64;
+    const int prec = (h->band_plan >= 2 && h->factor_precision == 32) ? 32 : 64;
     if (prec != h->band_prec) {
         for (void* p : h->band_factors) if (p) hipFree(p);
         for (int* p : h->band_pivots) if (p) hipFree(p);
@@ -285,7 +285,7 @@ static int band_ensure_slots(feasthip_ctx* h, int nslots) {
     if (missing > 0) {
         size_t free_b = 0, total_b = 0;
         // (multifrontal plan: the work arena and the substitution panels are transient buffers of about the factors' size again)
-        const double transient = h->band_plan == 3 ? (double)nslots * ((double)fh_mf_work_bytes(h) + 0.5 * (double)bytes) : 0.0;
+        const double transient = h->band_plan == 3 ? (double)nslots * ((double)fh_mf_work_bytes(h, prec) + 0.5 * (double)bytes) : 0.0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)missing * (double)bytes + transient > 0.92 * (double)free_b) {
             h->last_error = "banded LU: " + std::to_string(missing) + " factors of " + std::to_string(bytes >> 20) + " MiB do not fit the free device memory (" +
                             std::to_string(free_b >> 20) + " MiB)";
@@ -350,9 +350,9 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
         if ((rc = fh_get_buf(h, "bd_z", nf * sizeof(cplx), &p))) return rc;
         cplx* dz = (cplx*)p;
         FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
-        if ((rc = fh_mf_factor(h, nf, stores.data(), pvs.data(), dz, info_out))) return rc;
+        if ((rc = fh_mf_factor(h, h->band_prec, nf, stores.data(), pvs.data(), dz, info_out))) return rc;
         if (getenv("FH_DEBUG_TIMING"))
-            fprintf(stderr, "[feasthip] multifrontal LU: %d factorisations in %.1f ms\n", nf,
+            fprintf(stderr, "[feasthip] multifrontal LU: %d factorisations (%d-bit) in %.1f ms\n", nf, h->band_prec,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_factor).count());
         return 0;
     }
@@ -402,7 +402,7 @@ static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<in
         std::vector<void*> stores(nf);
         std::vector<int*> pvs(nf);
         for (int q = 0; q < nf; ++q) { stores[q] = h->band_factors[slots[q]]; pvs[q] = h->band_pivots[slots[q]]; }
-        return fh_mf_solve(h, nf, stores.data(), pvs.data(), RHS, rhs_stride, Y, stride, ld, m);
+        return fh_mf_solve(h, h->band_prec, nf, stores.data(), pvs.data(), RHS, rhs_stride, Y, stride, ld, m);
     }
     cplx** dabs; int** dpvs; int** dperms;
     if ((rc = band_pointer_arrays(h, slots, &dabs, &dpvs, &dperms))) return rc;

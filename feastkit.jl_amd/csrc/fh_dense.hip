@@ -737,7 +737,7 @@ __global__ __launch_bounds__(FH_BLOCK) void k_lu_trsm_mul(T* const* LUs, lu_geom
 // for the trailing matrix, which is then read and written once per 128 eliminated columns.
 template <int KC, typename T>
 __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, int k0, int kd, int r0, int r1, int c0,
-                                                       int c1, int TR, int TC) {
+                                                       int c1, int TR, int TC, int compact = 0) {
     T* A = LUs[blockIdx.y];
     __shared__ T Ls[KC][64];
     __shared__ T Us[KC][64];
@@ -745,11 +745,16 @@ __global__ __launch_bounds__(FH_BLOCK, 2) void k_lu_gemm(T* const* LUs, int N, i
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, so XCD x takes the
     // 8x8 super-tiles x, x+8, ... and walks one super-tile with 64 consecutive local slots:
     // its L2 then holds the 8 L row tiles and <= 8 U column tiles (2 MB at k = 128) being reused
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int SR = (TR + 7) >> 3;
-    const int sw = min(8, TC);                                 // super-tile: 8 row tiles x sw column tiles
-    const int st = (slot / (8 * sw)) * 8 + xcd, within = slot % (8 * sw);
-    const int tr = (st % SR) * 8 + (within & 7), tc = (st / SR) * sw + (within >> 3);
+    int tr, tc;
+    if (compact) {                                             // (the multifrontal fronts: small products in large batches, see k_lu_gemm_direct)
+        tr = blockIdx.x % TR; tc = blockIdx.x / TR;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int SR = (TR + 7) >> 3;
+        const int sw = min(8, TC);                             // super-tile: 8 row tiles x sw column tiles
+        const int st = (slot / (8 * sw)) * 8 + xcd, within = slot % (8 * sw);
+        tr = (st % SR) * 8 + (within & 7); tc = (st / SR) * sw + (within >> 3);
+    }
     if (tr >= TR || tc >= TC) return;
     const int i0 = r0 + tr * 64, cc0 = c0 + tc * 64;
     const int lane = t & 63, wave = t >> 6;
@@ -2178,7 +2183,8 @@ int fh_wband_solve(feasthip_ctx* h, int prec, int nf, void** dbases, int** dpvs,
 //                per-node factor store; the full n x n work matrices live in an arena only until their parents are assembled
 // Substitution (k_mf_fwd_* / k_mf_bwd_*): right-hand sides travel up the tree as front vectors (n x ld row-major panels, the
 // same extend-add maps), each group a batch for k_solve_diag[_inv] / k_solve_update; the solution travels down by gathers.
-// No atomics anywhere: bitwise reproducible.  complex128 only.
+// No atomics anywhere: bitwise reproducible.  complex128 factors, or complex64 factors (half the store, the f32 MFMA) behind the
+// caller's fp64 refinement loop (fh_dense_lu_refined, as for the dense and band factors).
 // =======================================================================================
 #include "fh_mf.hpp"
 
@@ -2355,9 +2361,9 @@ int fh_mf_make_plan(feasthip_ctx* h, int leaf) {
 }
 int fh_mf_max_front(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.max_n : 0; }
 double fh_mf_plan_flops(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.flops : 0.0; }
-size_t fh_mf_store_bytes(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.store_elems * sizeof(cplx) : 0; }
+size_t fh_mf_store_bytes(feasthip_ctx* h, int prec) { return h->mf ? ((fh_mf_state*)h->mf)->P.store_elems * (prec == 32 ? sizeof(cplxf) : sizeof(cplx)) : 0; }
 size_t fh_mf_pivot_ints(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.piv_ints : 0; }
-size_t fh_mf_work_bytes(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.work_elems * sizeof(cplx) : 0; }
+size_t fh_mf_work_bytes(feasthip_ctx* h, int prec) { return h->mf ? ((fh_mf_state*)h->mf)->P.work_elems * (prec == 32 ? sizeof(cplxf) : sizeof(cplx)) : 0; }
 
 // zero the work matrices of a group, 1 on the pad pivots
 template <typename T>
@@ -2432,42 +2438,42 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mf_store(T* const* W, T* const* S,
 
 // ---- substitution: front vectors are row-major n x LD panels; group g's panels start at row rhs_off * nf, matrix m = node * F + slot
 // forward, step 1: Z[m] = [rhs rows of the pivots (unpermuted); 0]
-template <int LD>
+template <int LD, typename T>
 __global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_load(const cplx* __restrict__ RHS, size_t rhs_stride, const int* __restrict__ perm, const mf_slot* slots, int F,
-                                                           cplx* Z, int n) {
+                                                           T* Z, int n) {
     const int m = blockIdx.y, s = m % F, node = m / F;
     const mf_slot sl = slots[s];
     const cplx* R = RHS + (size_t)node * rhs_stride;
-    cplx* z = Z + (size_t)m * n * LD;
+    T* z = Z + (size_t)m * n * LD;
     const size_t total = (size_t)n * LD;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         const int r = (int)(e / LD), c = (int)(e % LD);
-        z[e] = r < sl.npiv ? R[(size_t)perm[sl.piv0 + r] * LD + c] : cmake(0, 0);
+        z[e] = r < sl.npiv ? cvt<T>(R[(size_t)perm[sl.piv0 + r] * LD + c]) : LU_MK(0, 0);
     }
 }
 // forward, step 2: parent rows += the child's updated boundary rows (grid.y = child, grid.z = node)
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_add(const mf_kid* kids, const cplx* __restrict__ Ybase, cplx* Zp, const int* __restrict__ rel, int nf, int F_p, int n_p) {
+template <int LD, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_add(const mf_kid* kids, const T* __restrict__ Ybase, T* Zp, const int* __restrict__ rel, int nf, int F_p, int n_p) {
     const mf_kid kd = kids[blockIdx.y];
     const int node = blockIdx.z;
-    const cplx* yc = Ybase + ((size_t)kd.c_rhs_off * nf + ((size_t)node * kd.c_F + kd.c_slot) * kd.n_c + kd.np_c) * LD;
-    cplx* zp = Zp + ((size_t)node * F_p + kd.p_slot) * n_p * LD;
+    const T* yc = Ybase + ((size_t)kd.c_rhs_off * nf + ((size_t)node * kd.c_F + kd.c_slot) * kd.n_c + kd.np_c) * LD;
+    T* zp = Zp + ((size_t)node * F_p + kd.p_slot) * n_p * LD;
     const int* r = rel + kd.rel_off;
     const size_t total = (size_t)kd.nbnd * LD;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         const int i = (int)(e / LD), c = (int)(e % LD);
-        cplx* d = zp + (size_t)r[i] * LD + c;
-        const cplx v = yc[e];
-        *d = cmake(d->x + v.x, d->y + v.y);
+        T* d = zp + (size_t)r[i] * LD + c;
+        const T v = yc[e];
+        *d = LU_MK(d->x + v.x, d->y + v.y);
     }
 }
 // forward, step 3: Y[m] = rows of Z[m] in pivot order (rows < np), boundary rows as they are
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_perm(int* const* pivs, const cplx* __restrict__ Z, cplx* Y, int n, int np) {
+template <int LD, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_perm(int* const* pivs, const T* __restrict__ Z, T* Y, int n, int np) {
     const int m = blockIdx.y;
     const int* pr = pivs[m] + np;
-    const cplx* z = Z + (size_t)m * n * LD;
-    cplx* y = Y + (size_t)m * n * LD;
+    const T* z = Z + (size_t)m * n * LD;
+    T* y = Y + (size_t)m * n * LD;
     const size_t total = (size_t)n * LD;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         const int r = (int)(e / LD), c = (int)(e % LD);
@@ -2475,43 +2481,44 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mf_fwd_perm(int* const* pivs, cons
     }
 }
 // backward, step 1: boundary rows of Y[m] = the parent's solution rows (pad rows zero)
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_mf_bwd_load(const mf_slot* slots, int F, const cplx* Ybase, cplx* Y, const int* __restrict__ rel, int nf, int n, int np) {
+template <int LD, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_bwd_load(const mf_slot* slots, int F, const T* Ybase, T* Y, const int* __restrict__ rel, int nf, int n, int np) {
     const int m = blockIdx.y, s = m % F, node = m / F;
     const mf_slot sl = slots[s];
-    cplx* y = Y + ((size_t)m * n + np) * LD;
-    const cplx* yp = sl.p_rhs_off >= 0 ? Ybase + ((size_t)sl.p_rhs_off * nf + ((size_t)node * sl.p_F + sl.p_slot) * sl.p_n) * LD : nullptr;
+    T* y = Y + ((size_t)m * n + np) * LD;
+    const T* yp = sl.p_rhs_off >= 0 ? Ybase + ((size_t)sl.p_rhs_off * nf + ((size_t)node * sl.p_F + sl.p_slot) * sl.p_n) * LD : nullptr;
     const int* r = rel + sl.rel_off;
     const size_t total = (size_t)(n - np) * LD;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         const int i = (int)(e / LD), c = (int)(e % LD);
-        y[e] = (i < sl.nbnd && yp) ? yp[(size_t)r[i] * LD + c] : cmake(0, 0);
+        y[e] = (i < sl.nbnd && yp) ? yp[(size_t)r[i] * LD + c] : LU_MK(0, 0);
     }
 }
 // backward, last step: the pivots' solution rows go to the caller's panel
-template <int LD>
-__global__ __launch_bounds__(FH_BLOCK) void k_mf_scatter(const mf_slot* slots, int F, const cplx* __restrict__ Y, const int* __restrict__ perm, cplx* OUT, size_t out_stride, int n) {
+template <int LD, typename T>
+__global__ __launch_bounds__(FH_BLOCK) void k_mf_scatter(const mf_slot* slots, int F, const T* __restrict__ Y, const int* __restrict__ perm, cplx* OUT, size_t out_stride, int n) {
     const int m = blockIdx.y, s = m % F, node = m / F;
     const mf_slot sl = slots[s];
-    const cplx* y = Y + (size_t)m * n * LD;
+    const T* y = Y + (size_t)m * n * LD;
     cplx* o = OUT + (size_t)node * out_stride;
     const size_t total = (size_t)sl.npiv * LD;
     for (size_t e = (size_t)blockIdx.x * FH_BLOCK + threadIdx.x; e < total; e += (size_t)gridDim.x * FH_BLOCK) {
         const int r = (int)(e / LD), c = (int)(e % LD);
-        o[(size_t)perm[sl.piv0 + r] * LD + c] = y[e];
+        o[(size_t)perm[sl.piv0 + r] * LD + c] = cmake((double)y[e].x, (double)y[e].y);
     }
 }
 
 // pointer arrays of one call: per group and matrix (node-major, m = q * F + slot) the work matrix, the factor store, the
 // shifted U12 view and the pivots
-struct mf_ptrs { cplx** work; cplx** store; cplx** u12; int** piv; std::vector<size_t> off; };
-static int mf_pointer_arrays(feasthip_ctx* h, const fh_mf_state& S, int nf, void* const* stores, int* const* pivs, cplx* work, bool need_work, mf_ptrs& out) {
+template <typename T> struct mf_ptrs { T** work; T** store; T** u12; int** piv; std::vector<size_t> off; };
+template <typename T>
+static int mf_pointer_arrays(feasthip_ctx* h, const fh_mf_state& S, int nf, void* const* stores, int* const* pivs, T* work, bool need_work, mf_ptrs<T>& out) {
     const fh_mf::plan& P = S.P;
     const int ng = (int)P.groups.size();
     out.off.assign(ng + 1, 0);
     for (int g = 0; g < ng; ++g) out.off[g + 1] = out.off[g] + P.groups[g].fronts.size() * (size_t)nf;
     const size_t tot = out.off[ng];
-    std::vector<cplx*> hw(tot), hs(tot), hu(tot);
+    std::vector<T*> hw(tot), hs(tot), hu(tot);
     std::vector<int*> hp(tot);
     for (int g = 0; g < ng; ++g) {
         const fh_mf::group& G = P.groups[g];
@@ -2521,15 +2528,15 @@ static int mf_pointer_arrays(feasthip_ctx* h, const fh_mf_state& S, int nf, void
             for (size_t s = 0; s < F; ++s) {
                 const size_t m = out.off[g] + (size_t)q * F + s;
                 hw[m] = need_work ? work + (size_t)q * P.work_elems + G.work_off + s * G.work_per : nullptr;
-                hs[m] = (cplx*)stores[q] + G.store_off + s * G.store_per;
-                hu[m] = (cplx*)((uintptr_t)(hs[m] + u12) - (uintptr_t)((size_t)G.np * G.np * sizeof(cplx)));   // column c >= np of a leading-dimension-np view
+                hs[m] = (T*)stores[q] + G.store_off + s * G.store_per;
+                hu[m] = (T*)((uintptr_t)(hs[m] + u12) - (uintptr_t)((size_t)G.np * G.np * sizeof(T)));   // column c >= np of a leading-dimension-np view
                 hp[m] = pivs[q] + G.piv_off + s * 2 * (size_t)G.np;
             }
     }
     void* p;
     int rc;
     if ((rc = fh_get_buf(h, "mf_ptrs", 4 * tot * sizeof(void*), &p))) return rc;
-    out.work = (cplx**)p; out.store = out.work + tot; out.u12 = out.store + tot; out.piv = (int**)(out.u12 + tot);
+    out.work = (T**)p; out.store = out.work + tot; out.u12 = out.store + tot; out.piv = (int**)(out.u12 + tot);
     FH_CHECK(hipMemcpyAsync(out.work, hw.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(out.store, hs.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
     FH_CHECK(hipMemcpyAsync(out.u12, hu.data(), tot * sizeof(void*), hipMemcpyHostToDevice, h->stream));
@@ -2543,8 +2550,8 @@ static inline unsigned mf_blocks(size_t work, size_t per_block, unsigned cap) {
 }
 
 // Factor nf shifted matrices z_q B - A into stores[q] / pivs[q].  info_out[q] != 0: a zero or non-finite pivot in some front.
-int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* dz, std::vector<int>& info_out) {
-    typedef cplx T;
+template <typename T>
+static int mf_factor_t(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* dz, std::vector<int>& info_out) {
     fh_mf_state* S = (fh_mf_state*)h->mf;
     if (!S) { h->last_error = "multifrontal LU: no plan"; return FEASTHIP_ERROR_INTERNAL; }
     const fh_mf::plan& P = S->P;
@@ -2557,8 +2564,8 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
     if ((rc = fh_get_buf(h, "mf_work", (size_t)nf * P.work_elems * sizeof(T), &p))) return rc;
     T* work = (T*)p;
     const double t_work = since();
-    mf_ptrs ptr;
-    if ((rc = mf_pointer_arrays(h, *S, nf, stores, pivs, work, true, ptr))) return rc;
+    mf_ptrs<T> ptr;
+    if ((rc = mf_pointer_arrays<T>(h, *S, nf, stores, pivs, work, true, ptr))) return rc;
     const double t_ptrs = since();
     const size_t tot = ptr.off[ng];
     for (int g = 0; g < ng; ++g)
@@ -2627,7 +2634,8 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
             // workgroups were 95 % of the launch (51 ms for one k = 32 update of the leaf group)
             const int compact = (nmat > 64 || 2 * TR * TC <= full) ? 1 : 0;
             const dim3 grid(compact ? TR * TC : full, nmat);
-            if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC, compact);
+            if constexpr (sizeof(T) != sizeof(cplx)) hipLaunchKernelGGL((k_lu_gemm<LU_NB, T>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC, compact);
+            else if (m3_off) hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, false>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC, compact);
             else hipLaunchKernelGGL((k_lu_gemm_direct<LU_NB, T, true>), grid, dim3(FH_BLOCK), 0, h->stream, W, n, k0, kd, r0, r1, c0, c1, TR, TC, compact);
         };
         int* ginfo = dinfo + ptr.off[g];
@@ -2689,10 +2697,14 @@ int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs,
     }
     return 0;
 }
+// prec: 64 = complex128 factors, 32 = complex64 factors (the caller refines in fp64: fh_dense_lu_refined)
+int fh_mf_factor(feasthip_ctx* h, int prec, int nf, void* const* stores, int* const* pivs, const cplx* dz, std::vector<int>& info_out) {
+    if (prec == 32) return mf_factor_t<cplxf>(h, nf, stores, pivs, dz, info_out);
+    return mf_factor_t<cplx>(h, nf, stores, pivs, dz, info_out);
+}
 
-template <int LD>
-static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& ptr, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int m) {
-    typedef cplx T;
+template <int LD, typename T>
+static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs<T>& ptr, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int m) {
     const fh_mf::plan& P = S->P;
     const int ng = (int)P.groups.size();
     const int cta = std::max(1, std::min(LD / 16, (m + 15) / 16));
@@ -2722,18 +2734,18 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
         const size_t stride = (size_t)n * LD;
         T** ST = ptr.store + ptr.off[g];
         const unsigned gb = mf_blocks((size_t)n * LD, 4 * FH_BLOCK, 64);
-        hipLaunchKernelGGL((k_mf_fwd_load<LD>), dim3(gb, nmat), dim3(FH_BLOCK), 0, h->stream, RHS, rhs_stride, S->d_perm, S->d_slots + S->slot_off[g], F, Zg, n);
+        hipLaunchKernelGGL((k_mf_fwd_load<LD, T>), dim3(gb, nmat), dim3(FH_BLOCK), 0, h->stream, RHS, rhs_stride, S->d_perm, S->d_slots + S->slot_off[g], F, Zg, n);
         for (int side = 0; side < 2; ++side) {
             const size_t k0 = S->kid_off[side][g], k1 = side == 0 ? S->kid_off[1][g] : S->kid_off[0][g + 1];
             if (k1 > k0) {
                 int nbmax = 0;
                 for (int c : G.kids[side]) nbmax = std::max(nbmax, P.fronts[c].nbnd);
                 if (nbmax > 0)
-                    hipLaunchKernelGGL((k_mf_fwd_add<LD>), dim3(mf_blocks((size_t)nbmax * LD, 4 * FH_BLOCK, 64), (unsigned)(k1 - k0), nf), dim3(FH_BLOCK), 0, h->stream,
+                    hipLaunchKernelGGL((k_mf_fwd_add<LD, T>), dim3(mf_blocks((size_t)nbmax * LD, 4 * FH_BLOCK, 64), (unsigned)(k1 - k0), nf), dim3(FH_BLOCK), 0, h->stream,
                                        S->d_kids + k0, Y, Zg, S->d_rel, nf, F, n);
             }
         }
-        hipLaunchKernelGGL((k_mf_fwd_perm<LD>), dim3(gb, nmat), dim3(FH_BLOCK), 0, h->stream, ptr.piv + ptr.off[g], Zg, Yg, n, np);
+        hipLaunchKernelGGL((k_mf_fwd_perm<LD, T>), dim3(gb, nmat), dim3(FH_BLOCK), 0, h->stream, ptr.piv + ptr.off[g], Zg, Yg, n, np);
         const size_t i32 = fh_mf::inv32_elems(np);
         const lu_geom gd{n, np, (size_t)n * np, (size_t)n * np + i32};      // diagonal solves: bounded by the pivot block
         const lu_geom gu{n, n, (size_t)n * np, (size_t)n * np + i32};       // updates: all rows of the front
@@ -2757,7 +2769,7 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
         const lu_geom gd{n, np, (size_t)n * np, (size_t)n * np + i32};
         const lu_geom gu{n, n, (size_t)n * np, (size_t)n * np + i32};
         if (nb > 0) {
-            hipLaunchKernelGGL((k_mf_bwd_load<LD>), dim3(mf_blocks((size_t)nb * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F,
+            hipLaunchKernelGGL((k_mf_bwd_load<LD, T>), dim3(mf_blocks((size_t)nb * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F,
                                Y, Yg, S->d_rel, nf, n, np);
             // z1 -= U12 x2: U12 through its leading-dimension-np view (columns np .. n)
             const lu_geom g12{np, n, 0, 0};
@@ -2769,7 +2781,7 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
             if (K0 > 0)
                 hipLaunchKernelGGL((k_solve_update<LD, T>), dim3((K0 + 63) / 64, nmat), dim3(FH_BLOCK), 0, h->stream, ST, Zg, Yg, stride, gu, K0, LU_NB * kb, 0, K0, cta);
         }
-        hipLaunchKernelGGL((k_mf_scatter<LD>), dim3(mf_blocks((size_t)np * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F, Yg,
+        hipLaunchKernelGGL((k_mf_scatter<LD, T>), dim3(mf_blocks((size_t)np * LD, 4 * FH_BLOCK, 64), nmat), dim3(FH_BLOCK), 0, h->stream, S->d_slots + S->slot_off[g], F, Yg,
                            S->d_perm, OUT, out_stride, n);
         return 0;
     };
@@ -2779,17 +2791,23 @@ static int mf_solve_ld(feasthip_ctx* h, fh_mf_state* S, int nf, const mf_ptrs& p
     return 0;
 }
 
-// OUT[q] = (z_q B - A)^-1 RHS[q] with the factors of fh_mf_factor.  Panels row-major N x ld; rhs_stride = 0: one shared panel.
-int fh_mf_solve(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int ld, int m) {
+// OUT[q] = (z_q B - A)^-1 RHS[q] with the factors of fh_mf_factor.  Panels row-major N x ld (fp64 in and out: complex64 factors narrow
+// the right-hand side on the way into the front vectors and widen the solution on the way out); rhs_stride = 0: one shared panel.
+template <typename T>
+static int mf_solve_t(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int ld, int m) {
     fh_mf_state* S = (fh_mf_state*)h->mf;
     if (!S) { h->last_error = "multifrontal LU: no plan"; return FEASTHIP_ERROR_INTERNAL; }
-    mf_ptrs ptr;
+    mf_ptrs<T> ptr;
     int rc;
     const auto t_in = std::chrono::steady_clock::now();
-    if ((rc = mf_pointer_arrays(h, *S, nf, stores, pivs, nullptr, false, ptr))) return rc;
+    if ((rc = mf_pointer_arrays<T>(h, *S, nf, stores, pivs, nullptr, false, ptr))) return rc;
     struct report { std::chrono::steady_clock::time_point t0, t1; ~report() { if (getenv("FH_DEBUG_TIMING")) fprintf(stderr, "[feasthip] multifrontal solve: pointer arrays %.1f ms, buffers + launches %.1f ms (host)\n",
         std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count()); } } rep{t_in, std::chrono::steady_clock::now()};
-    if (ld == 16) return mf_solve_ld<16>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
-    if (ld == 32) return mf_solve_ld<32>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
-    return mf_solve_ld<64>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
+    if (ld == 16) return mf_solve_ld<16, T>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
+    if (ld == 32) return mf_solve_ld<32, T>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
+    return mf_solve_ld<64, T>(h, S, nf, ptr, RHS, rhs_stride, OUT, out_stride, m);
+}
+int fh_mf_solve(feasthip_ctx* h, int prec, int nf, void* const* stores, int* const* pivs, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int ld, int m) {
+    if (prec == 32) return mf_solve_t<cplxf>(h, nf, stores, pivs, RHS, rhs_stride, OUT, out_stride, ld, m);
+    return mf_solve_t<cplx>(h, nf, stores, pivs, RHS, rhs_stride, OUT, out_stride, ld, m);
 }

@@ -40,13 +40,13 @@ int fh_wband_solve(feasthip_ctx* h, int prec, int nf, void** dbases, int** dpvs,
                    cplx* Y, size_t stride, void* Yb, void* Zb, int ld, int m, int kl, int ku);
 
 // Multifrontal sparse LU (fh_dense.hip, symbolic phase fh_mf.hpp): plan from the host pattern, batched numeric factorisation
-// of nf shifted matrices into per-node stores, substitution through the elimination tree.  complex128 only.
+// of nf shifted matrices into per-node stores, substitution through the elimination tree.  prec 64: complex128 factors; 32: complex64 factors (refinement is the caller's).
 int fh_mf_make_plan(feasthip_ctx* h, int leaf);
 void fh_mf_free(feasthip_ctx* h);
 double fh_mf_plan_flops(feasthip_ctx* h);
 int fh_mf_max_front(feasthip_ctx* h);
-size_t fh_mf_store_bytes(feasthip_ctx* h);
+size_t fh_mf_store_bytes(feasthip_ctx* h, int prec);
 size_t fh_mf_pivot_ints(feasthip_ctx* h);
-size_t fh_mf_work_bytes(feasthip_ctx* h);
-int fh_mf_factor(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* dz, std::vector<int>& info_out);
-int fh_mf_solve(feasthip_ctx* h, int nf, void* const* stores, int* const* pivs, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int ld, int m);
+size_t fh_mf_work_bytes(feasthip_ctx* h, int prec);
+int fh_mf_factor(feasthip_ctx* h, int prec, int nf, void* const* stores, int* const* pivs, const cplx* dz, std::vector<int>& info_out);
+int fh_mf_solve(feasthip_ctx* h, int prec, int nf, void* const* stores, int* const* pivs, const cplx* RHS, size_t rhs_stride, cplx* OUT, size_t out_stride, int ld, int m);

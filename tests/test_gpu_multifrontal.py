@@ -106,6 +106,29 @@ def test_multifrontal_contour_apply_cache_and_reproducibility(engine, force_mf):
     assert np.array_equal(engine.download(dP3, 40), got)
 
 
+def test_multifrontal_complex64_factors_refined(engine, force_mf):
+    """factor_precision = 32 on the multifrontal plan: complex64 fronts (half the store), every solve refined in fp64 against the
+    CSR operator -- fp64 accuracy; without refinement the same factors give single precision only."""
+    A, B = grid_pencil(24, 18, 10, seed=77, cplx=True, unsym=True)
+    engine.set_problem(A, B)
+    engine.set_solver("banded", rtol=1e-13, factor_precision=32)
+    kl, ku, nbytes64, blocked = engine.band_plan()
+    assert blocked == 2
+    check_solve(engine, A, B, 0.4 + 0.6j, 48, tol=5e-12)
+    assert engine.last_stats["max_rel_residual"] <= 1e-12
+    engine.set_solver("banded", rtol=1.0, factor_precision=32)
+    n, m = A.shape[0], 48
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
+    dY, rc = engine.shifted_solve(0.4 + 0.6j, engine.upload(X), m)
+    S = (0.4 + 0.6j) * B - A
+    res32 = np.linalg.norm(S @ engine.download(dY, m) - X) / np.linalg.norm(X)
+    assert rc == 0 and 1e-9 < res32 < 1e-2, res32
+    # back to complex128 factors on the same handle: the slots are re-made
+    engine.set_solver("banded", rtol=1e-12, factor_precision=64)
+    check_solve(engine, A, B, 0.4 + 0.6j, 48, seed=6)
+
+
 def test_multifrontal_singular_shift_reports_lapack(engine, force_mf):
     n = 300
     A = sp.diags([np.arange(1.0, n + 1)], [0]).tocsr()
