@@ -43,7 +43,7 @@ def grid_pencil(nx, ny, nz, seed, cplx=False, unsym=False):
     ((20, 16, 9), 64, False, True, None),      # unsymmetric values on a symmetric pattern
     ((25, 20, 12), 33, True, True, "24"),      # small leaves: deep tree, many groups
     ((30, 30, 1), 40, False, False, "200"),    # 2-D, large leaves
-    ((40, 30, 14), 64, False, False, None),    # pivot blocks beyond 256: the 128-block inverses
+    ((34, 26, 12), 64, False, False, None),    # pivot blocks beyond 256: the 128-block inverses
 ])
 def test_multifrontal_solve_matches_superlu(engine, force_mf, monkeypatch, shape, m, cplx, unsym, leaf):
     if leaf:
