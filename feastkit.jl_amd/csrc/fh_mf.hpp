@@ -364,65 +364,72 @@ static inline int make_plan(int N, const std::vector<int>& rowptr, const std::ve
         }
     }
 
-    // ---- assembly list: every CSR entry goes to the front that owns the earlier-eliminated of its two indices
+    // ---- assembly list (every CSR entry goes to the front that owns the earlier-eliminated of its two indices) and
+    // extend-add maps, front by front over a scratch map new index -> row of the current front
     {
         std::vector<int> owner(N);                               // new index -> front
         for (int f = 0; f < nf; ++f) for (int p = 0; p < P.fronts[f].npiv; ++p) owner[P.fronts[f].piv0 + p] = f;
-        auto local_row = [&](const front& F, const group& G, int idx) -> int {     // new index -> row of the padded front, -1: absent
-            if (idx >= F.piv0 && idx < F.piv0 + F.npiv) return idx - F.piv0;
-            const int* b0 = P.bnd.data() + F.bnd_off;
-            const int* it = std::lower_bound(b0, b0 + F.nbnd, idx);
-            if (it == b0 + F.nbnd || *it != idx) return -1;
-            return G.np + (int)(it - b0);
-        };
-        struct item { int group; int dst; int src; };
-        std::vector<item> items;
+        const size_t nnz = (size_t)rowptr[N];
+        // entries bucketed by owning front (counting sort), B = I diagonals without an A entry appended per front
+        std::vector<int> erow(nnz), efront(nnz);
+        std::vector<size_t> fstart(nf + 1, 0);
         std::vector<char> has_diag(b_identity ? N : 0, 0);
-        for (int i = 0; i < N; ++i)
+        for (int i = 0; i < N; ++i) {
+            const int ni = P.iperm[i];
             for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                const int j = col[k];
-                const int ni = P.iperm[i], nj = P.iperm[j];
-                const int f = owner[std::min(ni, nj)];
-                const front& F = P.fronts[f];
-                const group& G = P.groups[F.group];
-                const int r = local_row(F, G, ni), c = local_row(F, G, nj);
-                if (r < 0 || c < 0) return 5;
-                const int dst = (int)((size_t)F.slot * G.work_per + (size_t)r + (size_t)c * G.n);
-                if (b_identity && i == j) { has_diag[i] = 1; items.push_back({F.group, ~dst, k}); }
-                else items.push_back({F.group, dst, k});
+                const int f = owner[std::min(ni, P.iperm[col[k]])];
+                erow[k] = i; efront[k] = f; fstart[f + 1]++;
+                if (b_identity && col[k] == i) has_diag[i] = 1;
             }
-        if (b_identity)
-            for (int i = 0; i < N; ++i) if (!has_diag[i]) {
-                const int ni = P.iperm[i];
-                const front& F = P.fronts[owner[ni]];
-                const group& G = P.groups[F.group];
-                const int r = ni - F.piv0;
-                items.push_back({F.group, ~(int)((size_t)F.slot * G.work_per + (size_t)r + (size_t)r * G.n), -1});
-            }
-        std::stable_sort(items.begin(), items.end(), [](const item& a, const item& c) { return a.group < c.group; });
-        P.asm_dst.resize(items.size()); P.asm_src.resize(items.size());
-        size_t q = 0;
-        for (int g = 0; g < (int)P.groups.size(); ++g) {
-            P.groups[g].asm_begin = q;
-            while (q < items.size() && items[q].group == g) { P.asm_dst[q] = items[q].dst; P.asm_src[q] = items[q].src; ++q; }
-            P.groups[g].asm_end = q;
         }
-        if (q != items.size()) return 5;
-
-        // ---- extend-add maps
+        for (int f = 0; f < nf; ++f) fstart[f + 1] += fstart[f];
+        std::vector<int> byfront(nnz);
+        {
+            std::vector<size_t> fill(fstart.begin(), fstart.end() - 1);
+            for (size_t k = 0; k < nnz; ++k) byfront[fill[efront[k]]++] = (int)k;
+        }
+        const int ngr = (int)P.groups.size();
+        std::vector<int> e_dst, e_src, e_grp;
+        e_dst.reserve(nnz + (b_identity ? N : 0)); e_src.reserve(e_dst.capacity()); e_grp.reserve(e_dst.capacity());
+        std::vector<int> pos(N, -1);
         P.rel.assign(P.bnd.size(), -1);
         for (int f = 0; f < nf; ++f) {
             const front& F = P.fronts[f];
-            if (F.parent < 0) continue;
-            const front& Pf = P.fronts[F.parent];
-            const group& Gp = P.groups[Pf.group];
-            for (int q2 = 0; q2 < F.nbnd; ++q2) {
-                const int r = local_row(Pf, Gp, P.bnd[F.bnd_off + q2]);
-                if (r < 0) return 6;
-                P.rel[F.bnd_off + q2] = r;
+            const group& G = P.groups[F.group];
+            for (int p = 0; p < F.npiv; ++p) pos[F.piv0 + p] = p;
+            for (int q = 0; q < F.nbnd; ++q) pos[P.bnd[F.bnd_off + q]] = G.np + q;
+            const size_t base = (size_t)F.slot * G.work_per;
+            for (size_t e = fstart[f]; e < fstart[f + 1]; ++e) {
+                const int k = byfront[e], i = erow[k], j = col[k];
+                const int r = pos[P.iperm[i]], c = pos[P.iperm[j]];
+                if (r < 0 || c < 0) return 5;
+                const int dst = (int)(base + (size_t)r + (size_t)c * G.n);
+                e_dst.push_back(b_identity && i == j ? ~dst : dst); e_src.push_back(k); e_grp.push_back(F.group);
             }
-            P.groups[Pf.group].kids[Pf.child[0] == f ? 0 : 1].push_back(f);
+            if (b_identity)
+                for (int p = 0; p < F.npiv; ++p) if (!has_diag[P.perm[F.piv0 + p]]) {
+                    e_dst.push_back(~(int)(base + (size_t)p + (size_t)p * G.n)); e_src.push_back(-1); e_grp.push_back(F.group);
+                }
+            for (int c : F.child) if (c >= 0) {
+                const front& C = P.fronts[c];
+                for (int q = 0; q < C.nbnd; ++q) {
+                    const int r = pos[P.bnd[C.bnd_off + q]];
+                    if (r < 0) return 6;
+                    P.rel[C.bnd_off + q] = r;
+                }
+                P.groups[F.group].kids[F.child[0] == c ? 0 : 1].push_back(c);
+            }
+            for (int p = 0; p < F.npiv; ++p) pos[F.piv0 + p] = -1;
+            for (int q = 0; q < F.nbnd; ++q) pos[P.bnd[F.bnd_off + q]] = -1;
         }
+        // counting sort by group: the list is read group by group on the device
+        std::vector<size_t> start(ngr + 1, 0);
+        for (int g : e_grp) start[g + 1]++;
+        for (int g = 0; g < ngr; ++g) start[g + 1] += start[g];
+        P.asm_dst.resize(e_dst.size()); P.asm_src.resize(e_dst.size());
+        for (int g = 0; g < ngr; ++g) { P.groups[g].asm_begin = start[g]; P.groups[g].asm_end = start[g + 1]; }
+        std::vector<size_t> fill(start.begin(), start.end() - 1);
+        for (size_t q = 0; q < e_dst.size(); ++q) { const size_t at = fill[e_grp[q]]++; P.asm_dst[at] = e_dst[q]; P.asm_src[at] = e_src[q]; }
     }
     return 0;
 }
