@@ -516,13 +516,18 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mgs_pick(const cplx* __restrict__ 
                                                         double* dstate) {
     __shared__ cplx red[FH_BLOCK];
     __shared__ double nrm[LD];
+    __shared__ int used[LD];
     const int t = threadIdx.x, c = t % LD, g = t / LD;
     constexpr int G = FH_BLOCK / LD;
     if (istate[2]) return;   // done
     cplx s = cmake(0, 0);
     for (int b = g; b < nblk; b += G) s = cadd(s, partial[(size_t)b * LD + c]);
     red[t] = s;
+    if (t < LD) used[t] = 0;
     __syncthreads();
+    // columns already chosen: perm[0..k) -- marked by k threads (one thread walking the list per candidate column was
+    // 4 096 dependent global loads at k = 64: 50 of this kernel's 66 us)
+    if (t < istate[0] && t < LD) used[istate[4 + t]] = 1;
     if (t < LD) {
         double tot = red[t].x;
         for (int k = 1; k < G; ++k) tot += red[t + k * LD].x;
@@ -532,12 +537,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mgs_pick(const cplx* __restrict__ 
     __syncthreads();
     if (t == 0) {
         const int k = istate[0];
-        // columns already chosen: perm[0..k)
         double best = -1.0; int bp = -1;
         for (int cc = 0; cc < m; ++cc) {
-            bool used = false;
-            for (int q = 0; q < k; ++q) if (istate[4 + q] == cc) used = true;
-            if (used) continue;
+            if (used[cc]) continue;
             if (nrm[cc] > best) { best = nrm[cc]; bp = cc; }
         }
         double rkk = (bp >= 0) ? sqrt(best) : 0.0;
@@ -593,13 +595,16 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mgs_coef(const cplx* __restrict__ 
                                                         const int* istate, int normalize, cplx* coef) {
     __shared__ cplx red[FH_BLOCK];
     __shared__ cplx dsum[LD];
+    __shared__ int taken[LD];
     const int t = threadIdx.x, c = t % LD, g = t / LD;
     constexpr int G = FH_BLOCK / LD;
     if (istate[2]) return;
     cplx s = cmake(0, 0);
     for (int b = g; b < nblk; b += G) s = cadd(s, partial[(size_t)b * LD + c]);
     red[t] = s;
+    if (t < LD) taken[t] = 0;
     __syncthreads();
+    if (t <= istate[0] && t < LD) taken[istate[4 + t]] = 1;                  // chosen columns, the pivot itself included
     if (t < LD) {
         cplx tot = red[t];
         for (int k = 1; k < G; ++k) tot = cadd(tot, red[t + k * LD]);
@@ -607,10 +612,9 @@ __global__ __launch_bounds__(FH_BLOCK) void k_mgs_coef(const cplx* __restrict__ 
     }
     __syncthreads();
     if (t < LD) {
-        const int k = istate[0], p = istate[3];
+        const int p = istate[3];
         const double dp = dsum[p].x;
-        bool used = (t >= m);
-        for (int q = 0; q <= k; ++q) if (istate[4 + q] == t) used = true;   // includes the pivot itself
+        const bool used = (t >= m) || taken[t] != 0;
         cplx cf = cmake(0, 0);
         if (!used && dp > 0.0) cf = cmake(dsum[t].x / dp, dsum[t].y / dp);
         if (t == p) cf = cmake(normalize && dp > 0.0 ? 1.0 / sqrt(dp) : 1.0, 0.0);
