@@ -197,3 +197,38 @@ def test_multifrontal_fuzz(engine, force_mf):
                 raise AssertionError(f"case {case}: {desc} m={m} cplx={cplx} leaf={os.environ['FH_MF_LEAF']} B={'I' if B is None else 'tri'}: {exc}")
         finally:
             del os.environ["FH_MF_LEAF"]
+
+
+def _residual_check(engine, A, B, z, m=32, tol=1e-11):
+    n = A.shape[0]
+    engine.set_problem(A, B)
+    engine.set_solver("banded")
+    assert engine.band_plan()[3] == 2
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
+    dY, rc = engine.shifted_solve(z, engine.upload(X), m)
+    assert rc == 0
+    Y = engine.download(dY, m)
+    S = z * (B if B is not None else sp.identity(n)) - A
+    res = np.linalg.norm(S @ Y - X) / np.linalg.norm(X)
+    assert res <= tol, res
+
+
+def test_multifrontal_large_patterns_by_residual(engine, force_mf):
+    """Sizes the host checker cannot follow (no SuperLU here: the residual of the solve in fp64 on the host): a 2-D grid of
+    360 000 unknowns, and an unstructured 2-D mesh stand-in (6 nearest neighbours of 120 000 random points) in a scrambled
+    numbering -- separators found on a graph without any grid structure."""
+    A, B, _ = workloads.laplacian_3d_pencil(600, 600, 1)
+    _residual_check(engine, A, B, 0.3 + 0.2j)
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(3)
+    n = 120000
+    pts = rng.random((n, 2))
+    _, idx = cKDTree(pts).query(pts, k=7)
+    rows = np.repeat(np.arange(n), 6)
+    W = sp.coo_matrix((-np.ones(len(rows)), (rows, idx[:, 1:].ravel())), shape=(n, n)).tocsr()
+    W = ((W + W.T) * 0.5).tocsr()
+    A = (W + sp.diags(-np.asarray(W.sum(axis=1)).ravel() + 0.1)).tocsr()
+    p = rng.permutation(n)
+    A = A[p][:, p].tocsr()
+    _residual_check(engine, A, None, 0.05 + 0.1j)
