@@ -335,6 +335,13 @@ static int band_pointer_arrays(feasthip_ctx* h, const std::vector<int>& which, c
     return 0;
 }
 
+// (fronts of a group) x (nodes of a call) is a grid dimension of the multifrontal kernels (FH_MF_NODES_PER_CALL: smaller batches, tests)
+static int mf_nodes_per_call(feasthip_ctx* h) {
+    int per = std::max(1, 65535 / std::max(1, fh_mf_max_group(h)));
+    if (getenv("FH_MF_NODES_PER_CALL")) per = std::max(1, std::min(per, atoi(getenv("FH_MF_NODES_PER_CALL"))));
+    return per;
+}
+
 static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, const std::vector<cplx>& zlist, std::vector<int>& info_out) {
     const int nf = (int)which.size();
     info_out.assign(nf, 0);
@@ -350,7 +357,14 @@ static int band_factor_batch(feasthip_ctx* h, const std::vector<int>& which, con
         if ((rc = fh_get_buf(h, "bd_z", nf * sizeof(cplx), &p))) return rc;
         cplx* dz = (cplx*)p;
         FH_CHECK(hipMemcpyAsync(dz, zlist.data(), nf * sizeof(cplx), hipMemcpyHostToDevice, h->stream));
-        if ((rc = fh_mf_factor(h, h->band_prec, nf, stores.data(), pvs.data(), dz, info_out))) return rc;
+        // (fronts of a group) x (nodes of a call) is a grid dimension: node batches for long contours
+        const int per_call = mf_nodes_per_call(h);
+        for (int q0 = 0; q0 < nf; q0 += per_call) {
+            const int cnt = std::min(per_call, nf - q0);
+            std::vector<int> info_part;
+            if ((rc = fh_mf_factor(h, h->band_prec, cnt, stores.data() + q0, pvs.data() + q0, dz + q0, info_part))) return rc;
+            for (int q = 0; q < cnt; ++q) info_out[q0 + q] = info_part[q];
+        }
         if (getenv("FH_DEBUG_TIMING"))
             fprintf(stderr, "[feasthip] multifrontal LU: %d factorisations (%d-bit) in %.1f ms\n", nf, h->band_prec,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_factor).count());
@@ -402,7 +416,12 @@ static int band_solve_batch(feasthip_ctx* h, int ld, int m, const std::vector<in
         std::vector<void*> stores(nf);
         std::vector<int*> pvs(nf);
         for (int q = 0; q < nf; ++q) { stores[q] = h->band_factors[slots[q]]; pvs[q] = h->band_pivots[slots[q]]; }
-        return fh_mf_solve(h, h->band_prec, nf, stores.data(), pvs.data(), RHS, rhs_stride, Y, stride, ld, m);
+        const int per_call = mf_nodes_per_call(h);
+        for (int q0 = 0; q0 < nf; q0 += per_call) {
+            const int cnt = std::min(per_call, nf - q0);
+            if ((rc = fh_mf_solve(h, h->band_prec, cnt, stores.data() + q0, pvs.data() + q0, RHS + (size_t)q0 * rhs_stride, rhs_stride, Y + (size_t)q0 * stride, stride, ld, m))) return rc;
+        }
+        return 0;
     }
     cplx** dabs; int** dpvs; int** dperms;
     if ((rc = band_pointer_arrays(h, slots, &dabs, &dpvs, &dperms))) return rc;

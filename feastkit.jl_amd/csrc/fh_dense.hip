@@ -2359,6 +2359,13 @@ int fh_mf_make_plan(feasthip_ctx* h, int leaf) {
     }
     return 0;
 }
+// largest number of fronts in one group: (fronts x nodes of a call) is a grid dimension, the caller batches its nodes accordingly
+int fh_mf_max_group(feasthip_ctx* h) {
+    if (!h->mf) return 0;
+    size_t m = 1;
+    for (const fh_mf::group& G : ((fh_mf_state*)h->mf)->P.groups) m = std::max(m, G.fronts.size());
+    return (int)m;
+}
 int fh_mf_max_front(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.max_n : 0; }
 double fh_mf_plan_flops(feasthip_ctx* h) { return h->mf ? ((fh_mf_state*)h->mf)->P.flops : 0.0; }
 size_t fh_mf_store_bytes(feasthip_ctx* h, int prec) { return h->mf ? ((fh_mf_state*)h->mf)->P.store_elems * (prec == 32 ? sizeof(cplxf) : sizeof(cplx)) : 0; }

@@ -45,6 +45,7 @@ int fh_mf_make_plan(feasthip_ctx* h, int leaf);
 void fh_mf_free(feasthip_ctx* h);
 double fh_mf_plan_flops(feasthip_ctx* h);
 int fh_mf_max_front(feasthip_ctx* h);
+int fh_mf_max_group(feasthip_ctx* h);
 size_t fh_mf_store_bytes(feasthip_ctx* h, int prec);
 size_t fh_mf_pivot_ints(feasthip_ctx* h);
 size_t fh_mf_work_bytes(feasthip_ctx* h, int prec);

@@ -79,7 +79,7 @@ def test_multifrontal_random_patterns_match_superlu(engine, force_mf, n, band, d
     check_solve(engine, A, B, 0.3 + 0.8j, m)
 
 
-def test_multifrontal_contour_apply_cache_and_reproducibility(engine, force_mf):
+def test_multifrontal_contour_apply_cache_and_reproducibility(engine, force_mf, monkeypatch):
     A, B, _ = workloads.laplacian_3d_pencil(30, 20, 13)       # (not the band test's 30 x 20 x 12: the engine keeps the plan of a matrix it already holds)
     n = A.shape[0]
     engine.set_problem(A, B)
@@ -104,6 +104,12 @@ def test_multifrontal_contour_apply_cache_and_reproducibility(engine, force_mf):
     dP3, status, st3 = engine.contour_apply(engine.upload(Q), 40)
     assert st3["factorizations"] == 8
     assert np.array_equal(engine.download(dP3, 40), got)
+    # node batches (long contours: fronts x nodes is a grid dimension): 3 + 3 + 2 nodes per call, the same bits again
+    monkeypatch.setenv("FH_MF_NODES_PER_CALL", "3")
+    engine.free_factors()
+    dP4, status, st4 = engine.contour_apply(engine.upload(Q), 40)
+    assert st4["factorizations"] == 8 and np.all(status[:8] == 0)
+    assert np.array_equal(engine.download(dP4, 40), got)
 
 
 def test_multifrontal_complex64_factors_refined(engine, force_mf):
