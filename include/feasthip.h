@@ -56,14 +56,17 @@ enum {
                                       src/interfaces/feast_matfree.jl:716)                 */
     FEASTHIP_SOLVER_GMRES = 2,     /* :gmres   -- batched restarted GMRES(m)
                                       (src/sparse/feast_sparse.jl:183-188)                 */
-    FEASTHIP_SOLVER_BANDED = 4,    /* sparse DIRECT solver for CSR input: batched band LU (ZGBTRF/ZGBTRS semantics,
-                                      partial pivoting) per quadrature node, factors cached across refinement loops.
-                                      The direct solver of the banded drivers (src/banded/feast_banded.jl:100-150) and
-                                      the build's counterpart of the sparse drivers' default `lu(z B - A)` (UMFPACK,
-                                      src/sparse/feast_sparse.jl:339-342): a narrow band is eliminated as stored; any
-                                      other pattern is renumbered by reverse Cuthill-McKee and eliminated by a blocked
-                                      band LU on the dense MFMA kernels (fill confined to the band; memory
-                                      16 N (2 kl + ku + 256) bytes per node -- see feasthip_band_plan)          */
+    FEASTHIP_SOLVER_BANDED = 4,    /* sparse DIRECT solver for CSR input: one LU of z B - A per quadrature node, factors
+                                      cached across refinement loops.  The direct solver of the banded drivers
+                                      (src/banded/feast_banded.jl:100-150) and the build's counterpart of the sparse
+                                      drivers' default `lu(z B - A)` (UMFPACK, src/sparse/feast_sparse.jl:339-342).
+                                      A narrow band is eliminated as stored (ZGBTRF/ZGBTRS semantics); any other
+                                      pattern by a multifrontal LU on a nested-dissection tree (batched dense fronts on
+                                      the MFMA LU kernels, partial pivoting inside the fully-summed blocks) when that is
+                                      less than half the work of the alternative: reverse Cuthill-McKee + a blocked band
+                                      LU on the same kernels (fill confined to the band, 16 N (2 kl + ku + 256) bytes
+                                      per node).  feasthip_band_plan / feasthip_direct_plan_flops say which, and what
+                                      it costs                                                               */
     FEASTHIP_SOLVER_COCG = 3       /* conjugate-orthogonal CG for the complex-SYMMETRIC shifted
                                       systems that real-symmetric A, B produce (one operator
                                       application per iteration); not in the reference      */
