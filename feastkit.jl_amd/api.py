@@ -50,12 +50,13 @@ def _sparse_direct_solver(A, B, nodes, budget_bytes=32 << 30, dense_limit=12288)
     return "krylov"
 
 
-# `solver=:direct` on a sparse Hermitian pencil beyond the narrow-band / dense windows: the band LU is taken outright when all
-# its factorisations together cost at most this many flop (8 N kl (kl + ku) per node), else the Krylov path runs first with
-# the direct solver as its fallback.  OFF by default (0): the block steps of the band LU are a chain of panel kernels, ~0.4 s
-# for N = 50 000 however thin the band, and the inexact Krylov path is at 0.3 s on the 2-D / thin 3-D pencils tried (first
-# calls, N = 50 000: 400 x 125 grid 0.48 s direct / 0.53 s Krylov; 160 x 160 x 2: 0.72 / 0.30; 100 x 100 x 5: 0.76 / 0.30).
-_DIRECT_FLOPS = float(os.environ.get("FEASTKIT_DIRECT_FLOPS", "0"))
+# `solver=:direct` on a sparse Hermitian pencil beyond the narrow-band / dense windows: the sparse direct solver (multifrontal
+# LU, or the band LU) is taken outright when all its factorisations together cost at most this many flop (feasthip_direct_plan_flops
+# x local nodes), else the Krylov path runs first with the direct solver as its fallback.  4e11: with the multifrontal plan a 2-D
+# pencil of 50 000 unknowns (1e11 in all) is a 0.1 s direct call against 0.5 s of Krylov loops, while cfg 3 (1.7e12 in all: 0.19 s)
+# stays with the Krylov path (0.16 s).  With the band LU alone (round 3) the switch was off: its block steps are a chain of panel
+# kernels, ~0.4 s for N = 50 000 however thin the band.  0: never.
+_DIRECT_FLOPS = float(os.environ.get("FEASTKIT_DIRECT_FLOPS", "4e11"))
 
 
 def _direct_label(eng):
@@ -276,7 +277,10 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
                 plan["t_direct"] = None
                 if _band_direct_fits(eng, A, B, int(fpm[2])):
                     kl, ku, _nb, _blk = eng.band_plan()
-                    plan["t_direct"] = 0.3 + (N / 128.0) * 1.5e-3 + 8.0 * N * kl * (kl + ku) * int(fpm[2]) / 2e13
+                    if _blk == 2:      # multifrontal plan: measured 0.19 s for cfg 3 (1.05e11 flop per node, 16 nodes)
+                        plan["t_direct"] = 0.08 + eng.direct_plan_flops() * int(fpm[2]) / 1.3e13
+                    else:
+                        plan["t_direct"] = 0.3 + (N / 128.0) * 1.5e-3 + 8.0 * N * kl * (kl + ku) * int(fpm[2]) / 2e13
             if plan["t_direct"] is None:
                 return False
             fin = [e for e in eps if np.isfinite(e) and e > 0]

@@ -272,7 +272,7 @@ def test_default_call_noncommuting_pencils_full_size(engine, name):
     diffusion operators in 3-D and 2-D with a random lumped mass matrix or a second, independently weighted operator as
     B; no closed-form spectrum).  CPU answer: scipy's shift-invert Lanczos (ARPACK + SuperLU) on the same matrices.
     feast(A, B, (Emin, Emax); M0=64, fpm[2]=16) must return every eigenvalue of the interval with residuals
-    recomputed on the host <= 1e-11, with the contour policy engaged."""
+    recomputed on the host <= 1e-11, with the contour policy engaged (3-D) or through the sparse direct solver (2-D: cheap factorisations)."""
     import scipy.sparse.linalg as spla
     dims, kind = _PENCILS[name]
     A, B = fk.workloads.variable_coefficient_pencil(dims, kind)
@@ -285,8 +285,14 @@ def test_default_call_noncommuting_pencils_full_size(engine, name):
     assert np.abs(np.sort(r.lambda_) - w[:44]).max() <= 1e-9 * w[43]
     res = np.linalg.norm(A @ r.q - (B @ r.q) * r.lambda_, axis=0) / np.maximum(np.abs(r.lambda_), 1.0) / np.linalg.norm(r.q, axis=0)
     assert res.max() <= 1e-11
-    pol = r.stats["contour_policy"]["fpm18_per_loop"]
-    assert min(pol) > 100 and r.loop <= 16
+    used = (r.stats.get("solver_substitution") or {}).get("used", "")
+    if used.split()[0] in ("multifrontal", "band"):
+        # the 2-D pencil: all 16 factorisations together are under the direct solver's flop threshold (api._DIRECT_FLOPS), the
+        # default `solver=:direct` is then served directly -- exact solves, two or three loops
+        assert name == "diag_mass_2d" and r.loop <= 3 and r.stats["krylov_iterations"] == 0
+    else:
+        pol = r.stats["contour_policy"]["fpm18_per_loop"]
+        assert min(pol) > 100 and r.loop <= 16
 
 
 @pytest.mark.parametrize("aspect,cap", [(4000, 50), (100, 100)])

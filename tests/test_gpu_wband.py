@@ -143,10 +143,11 @@ def test_sparse_direct_interior_interval_full_size():
     assert (np.linalg.norm(R, axis=0) / np.maximum(np.abs(res.lambda_[:res.M]), 1.0)).max() <= 1e-10
 
 
-def test_default_call_falls_back_to_the_direct_solver(engine):
+def test_default_call_falls_back_to_the_direct_solver(engine, monkeypatch):
     """`feast(A, B, interval)` with every keyword at its default, on an interval inside the spectrum: the Krylov sweeps the
     default maps to (beyond the band / dense windows) stop with info = 5; solver=:direct was what the caller asked for, so
     the call then runs the sparse direct solver and returns what the reference's default would have."""
+    monkeypatch.setattr(fk.api, "_DIRECT_FLOPS", 0.0)                     # (this small pencil would be served directly at once: the fallback is the subject)
     A, B, lam = workloads.laplacian_3d_pencil(30, 24, 18)                 # N = 12 960: beyond the dense window
     mid = 2.0
     order = np.argsort(np.abs(lam - mid))
