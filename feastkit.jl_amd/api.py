@@ -228,7 +228,8 @@ def feast(A, B=None, interval=None, *, M0=10, fpm=None, backend="hip", solver="d
         if solver == "dense":
             A, B, solver = _densify(A), _densify(B), "direct"
             substituted = {"requested": "direct", "used": "dense LU of the expanded matrix"}
-        elif solver == "krylov" and group is None and _band_direct_fits(eng, A, B, int(fpm[2]), max_flops=_DIRECT_FLOPS):
+        elif (solver == "krylov" and group is None and _DIRECT_FLOPS > 0 and A.shape[0] <= 400_000     # (beyond: the plan itself -- host nested dissection -- is no longer small change)
+              and _band_direct_fits(eng, A, B, int(fpm[2]), max_flops=_DIRECT_FLOPS)):
             # a band the direct solver eliminates in a fraction of a second (2-D problems, thin 3-D ones): the reference's own
             # default -- a direct factorisation per node, exact solves, two or three loops -- is then also the faster one
             # (measured: DESIGN.md section 5); wider bands keep the Krylov fast path with the direct solver as its fallback
